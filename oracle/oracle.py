@@ -1,0 +1,262 @@
+"""ctypes front-end of the CPU oracle (oracle/oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg, never by the product package.  See oracle.c for the parity status
+(mapper path pinned by tests/golden; EKF and map_merger rasterise "parity unpinned").
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "liboracle.so")
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        L = C.CDLL(_SO)
+        vp, i32, i64, f64 = C.c_void_p, C.c_int, C.c_long, C.c_double
+        L.qso_create.restype = vp
+        L.qso_create.argtypes = [i32, f64, f64, f64, f64, i32, i32]
+        L.qso_destroy.argtypes = [vp]
+        L.qso_set_offset.argtypes = [vp, i32, f64]
+        L.qso_feed.restype = i32
+        L.qso_feed.argtypes = [vp, vp, i32]
+        L.qso_feed_stream.restype = i64
+        L.qso_feed_stream.argtypes = [vp, vp, i64, i64, vp]
+        L.qso_update_rays.argtypes = [vp, vp, vp, vp, vp, vp, i64]
+        L.qso_world_to_grid.argtypes = [vp, vp, i64, i32, vp]
+        L.qso_bresenham.restype = i64
+        L.qso_bresenham.argtypes = [i64, i64, i64, i64, vp, i64]
+        for name in ("qso_grid", "qso_hits", "qso_misses", "qso_poses", "qso_pose_agents",
+                     "qso_hit_points", "qso_hit_agent_sensor"):
+            getattr(L, name).restype = vp
+            getattr(L, name).argtypes = [vp]
+        for name in ("qso_n_nodes", "qso_n_landmarks", "qso_n_closures"):
+            getattr(L, name).restype = i64
+            getattr(L, name).argtypes = [vp, i32]
+        for name in ("qso_n_poses", "qso_n_hits", "qso_n_rays", "qso_n_cells_written"):
+            getattr(L, name).restype = i64
+            getattr(L, name).argtypes = [vp]
+        L.qso_drift.argtypes = [vp, i32, vp]
+        L.qso_closures.argtypes = [vp, i32, vp, vp]
+        L.qso_landmarks.argtypes = [vp, i32, vp, vp]
+        L.qso_zone.restype = i32
+        L.qso_zone.argtypes = [vp, i32, vp]
+        L.qso_zone_packet.argtypes = [vp, i32, i32, vp]
+        L.qso_logodds.argtypes = [vp, C.c_float, C.c_float, C.c_float, C.c_float, vp]
+        L.qso_grid_to_pcd.restype = i64
+        L.qso_grid_to_pcd.argtypes = [vp, i32, i32, f64, f64, f64, vp, i64]
+        L.qso_rasterise.restype = i32
+        L.qso_rasterise.argtypes = [vp, i64, f64, vp, vp, vp]
+        L.qso_ekf_init.argtypes = [vp, f64, vp]
+        L.qso_ekf_predict.argtypes = [vp, f64, f64]
+        L.qso_ekf_update.argtypes = [vp, f64, f64]
+        L.qso_ekf_packet.argtypes = [vp, vp, f64, f64, f64, f64, f64, f64]
+        _lib = L
+    return _lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _view(ptr, shape, dtype):
+    n = int(np.prod(shape))
+    if n == 0 or not ptr:
+        return np.zeros(shape, dtype=dtype)
+    buf = (C.c_char * (n * np.dtype(dtype).itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype).reshape(shape).copy()
+
+
+class OracleMapper:
+    """The reference mapper's per-packet path (dual_bot_mapper.py:826-945) on the CPU."""
+
+    def __init__(self, size=200, res=0.05, ox=-5.0, oy=-5.0, separation=0.0,
+                 max_agent=2, bots_per_graph=0):
+        self.size, self.res, self.ox, self.oy = size, res, ox, oy
+        self.max_agent = max_agent
+        self.bots_per_graph = bots_per_graph if bots_per_graph > 0 else max_agent
+        self.n_graphs = (max_agent + self.bots_per_graph - 1) // self.bots_per_graph
+        self._h = lib().qso_create(size, res, ox, oy, separation, max_agent, bots_per_graph)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().qso_destroy(self._h)
+            self._h = None
+
+    def set_offset(self, bot, off_x):
+        lib().qso_set_offset(self._h, bot, off_x)
+
+    def feed(self, datagram: bytes) -> int:
+        b = np.frombuffer(datagram, dtype=np.uint8) if len(datagram) else np.zeros(1, np.uint8)
+        return lib().qso_feed(self._h, _ptr(b), len(datagram))
+
+    def feed_stream(self, buf, lengths=None) -> int:
+        """buf: uint8 [n, stride]; lengths: uint16 [n] or None (all == stride)."""
+        buf = np.ascontiguousarray(buf, dtype=np.uint8)
+        n, stride = buf.shape
+        lp = None
+        if lengths is not None:
+            lengths = np.ascontiguousarray(lengths, dtype=np.uint16)
+            lp = _ptr(lengths)
+        return lib().qso_feed_stream(self._h, _ptr(buf), n, stride, lp)
+
+    def update_rays(self, rx, ry, hx, hy, valid):
+        a = [np.ascontiguousarray(v, dtype=np.float64) for v in (rx, ry, hx, hy)]
+        v = np.ascontiguousarray(valid, dtype=np.uint8)
+        lib().qso_update_rays(self._h, *[_ptr(x) for x in a], _ptr(v), len(v))
+
+    def world_to_grid(self, w, axis=0):
+        w = np.ascontiguousarray(w, dtype=np.float64)
+        out = np.empty(len(w), dtype=np.int64)
+        lib().qso_world_to_grid(self._h, _ptr(w), len(w), axis, _ptr(out))
+        return out
+
+    @property
+    def grid(self):
+        return _view(lib().qso_grid(self._h), (self.size, self.size), np.int8)
+
+    @property
+    def hits(self):
+        return _view(lib().qso_hits(self._h), (self.size, self.size), np.int32)
+
+    @property
+    def misses(self):
+        return _view(lib().qso_misses(self._h), (self.size, self.size), np.int32)
+
+    def logodds(self, l_occ=0.85, l_free=0.4, lmin=-2.0, lmax=3.5):
+        out = np.empty((self.size, self.size), dtype=np.float32)
+        lib().qso_logodds(self._h, l_occ, l_free, lmin, lmax, _ptr(out))
+        return out
+
+    @property
+    def poses(self):
+        return _view(lib().qso_poses(self._h), (lib().qso_n_poses(self._h), 3), np.float64)
+
+    @property
+    def pose_agents(self):
+        return _view(lib().qso_pose_agents(self._h), (lib().qso_n_poses(self._h),), np.int32)
+
+    @property
+    def hit_points(self):
+        return _view(lib().qso_hit_points(self._h), (lib().qso_n_hits(self._h), 2), np.float64)
+
+    @property
+    def hit_agent_sensor(self):
+        return _view(lib().qso_hit_agent_sensor(self._h), (lib().qso_n_hits(self._h),), np.int32)
+
+    @property
+    def n_rays(self):
+        return lib().qso_n_rays(self._h)
+
+    @property
+    def n_cells_written(self):
+        return lib().qso_n_cells_written(self._h)
+
+    def n_nodes(self, graph=0):
+        return lib().qso_n_nodes(self._h, graph)
+
+    def drift(self, bot):
+        out = np.zeros(2)
+        lib().qso_drift(self._h, bot, _ptr(out))
+        return out
+
+    def closures(self, graph=0):
+        n = lib().qso_n_closures(self._h, graph)
+        idx = np.zeros((n, 2), dtype=np.int64)
+        corr = np.zeros((n, 2), dtype=np.float64)
+        if n:
+            lib().qso_closures(self._h, graph, _ptr(idx), _ptr(corr))
+        return idx, corr
+
+    def landmarks(self, graph=0):
+        n = lib().qso_n_landmarks(self._h, graph)
+        xy = np.zeros((n, 2), dtype=np.float64)
+        ti = np.zeros((n, 2), dtype=np.int64)
+        if n:
+            lib().qso_landmarks(self._h, graph, _ptr(xy), _ptr(ti))
+        return xy, ti
+
+    def zone(self, bot):
+        out = np.zeros(4)
+        ok = lib().qso_zone(self._h, bot, _ptr(out))
+        return out if ok else None
+
+    def zone_packet(self, bot, online=True) -> bytes:
+        out = np.zeros(20, dtype=np.uint8)
+        lib().qso_zone_packet(self._h, bot, int(online), _ptr(out))
+        return out.tobytes()
+
+
+def bresenham(x0, y0, x1, y1):
+    cap = max(abs(x1 - x0), abs(y1 - y0)) + 1
+    out = np.zeros((cap, 2), dtype=np.int64)
+    n = lib().qso_bresenham(x0, y0, x1, y1, _ptr(out), cap)
+    assert n == cap
+    return out
+
+
+def grid_to_pcd(data, res, ox, oy):
+    data = np.ascontiguousarray(data, dtype=np.int8)
+    h, w = data.shape
+    n = lib().qso_grid_to_pcd(_ptr(data), h, w, res, ox, oy, None, 0)
+    xy = np.zeros((n, 2), dtype=np.float64)
+    if n:
+        lib().qso_grid_to_pcd(_ptr(data), h, w, res, ox, oy, _ptr(xy), n)
+    return xy
+
+
+def rasterise(xy, res):
+    xy = np.ascontiguousarray(xy, dtype=np.float64)
+    dims = np.zeros(2, dtype=np.int32)
+    origin = np.zeros(2, dtype=np.float64)
+    if not lib().qso_rasterise(_ptr(xy), len(xy), res, _ptr(dims), _ptr(origin), None):
+        return None, None
+    grid = np.empty((int(dims[0]), int(dims[1])), dtype=np.int8)
+    lib().qso_rasterise(_ptr(xy), len(xy), res, _ptr(dims), _ptr(origin), _ptr(grid))
+    return grid, origin
+
+
+class OracleEKF:
+    """Firmware EKF (AgentFirmware_Bot1/ekf.cpp) + the build-defined telemetry wiring."""
+
+    STRIDE = 44
+
+    def __init__(self, n_bots):
+        self.f = np.zeros((n_bots, self.STRIDE), dtype=np.float64)
+        self.prev = np.zeros((n_bots, 4), dtype=np.float64)
+
+    def init(self, b, t, x0):
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        lib().qso_ekf_init(_ptr(self.f[b]), t, _ptr(x0))
+
+    def predict(self, b, omega_m, t):
+        lib().qso_ekf_predict(_ptr(self.f[b]), omega_m, t)
+
+    def update(self, b, z_v, z_omega):
+        lib().qso_ekf_update(_ptr(self.f[b]), z_v, z_omega)
+
+    def packet(self, b, t, x, y, yaw, enc, metres_per_tick):
+        lib().qso_ekf_packet(_ptr(self.f[b]), _ptr(self.prev[b]), t, x, y, yaw, enc, metres_per_tick)
+
+    def state(self, b):
+        return self.f[b, :6].copy()
+
+    def cov(self, b):
+        return self.f[b, 6:42].reshape(6, 6).copy()

@@ -1,0 +1,379 @@
+#!/usr/bin/env python3
+"""Golden-vector generator.  RUNS ONLY IN THE BUILD CONTAINER (needs /root/reference).
+
+It imports the reference's own Python (server_nodes/dual_bot_mapper.py with an empty
+stand-in for the missing `pygame` *module object*, and
+simulation_tools/generate_fake_dual_session.py) and drives the reference classes in the
+order the reference's main() drives them (dual_bot_mapper.py:826-945).  What it writes
+under tests/golden/ is data only: input byte streams and the reference's outputs.
+
+    python tests/golden/make_golden.py
+
+Outputs (all loadable with numpy.load(allow_pickle=False) / json):
+    session_telemetry.csv      the generator's telemetry.csv (687 rows, seed 42)
+    kat.json                   scalar known-answer values (sizes, world_to_grid, hashes)
+    bresenham_d40.npz          exhaustive _bresenham table for |dx|,|dy| <= 40
+    update_ray_cases.npz       single update_ray() calls on a small grid
+    <scenario>.npz             datagram stream + reference outputs for that scenario
+"""
+import csv
+import hashlib
+import importlib.util
+import json
+import math
+import os
+import random
+import struct
+import sys
+import tempfile
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference"
+
+
+def load_reference():
+    for name in ("pygame", "pygame.gfxdraw"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["pygame"].gfxdraw = sys.modules["pygame.gfxdraw"]
+    spec = importlib.util.spec_from_file_location(
+        "ref_dual_bot_mapper", os.path.join(REF, "server_nodes", "dual_bot_mapper.py"))
+    mapper = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mapper)
+    spec = importlib.util.spec_from_file_location(
+        "ref_generate_fake", os.path.join(REF, "simulation_tools", "generate_fake_dual_session.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    return mapper, gen
+
+
+def run_generator(gen):
+    """Run the reference generator with its output redirected to a temp dir."""
+    tmp = tempfile.mkdtemp(prefix="qs_golden_")
+    gen.__file__ = os.path.join(tmp, "generate_fake_dual_session.py")
+    gen.main()
+    out = os.path.join(tmp, "server_nodes", "logs", "dual_session_20260611_062145")
+    with open(os.path.join(out, "telemetry.csv"), "rb") as f:
+        telem = f.read()
+    with open(os.path.join(out, "pointcloud.csv"), "rb") as f:
+        cloud = f.read()
+    return telem, cloud
+
+
+def telemetry_to_packets(mapper, telem_bytes):
+    """telemetry.csv rows, in file order -> list of 42-byte QuasarPacket v2 datagrams."""
+    rows = list(csv.DictReader(telem_bytes.decode().splitlines()))
+    pkts, times = [], []
+    for r in rows:
+        pkts.append(struct.pack(
+            mapper.PACKET_FMT, b"QSRL", int(r["agent"]), float(r["x"]), float(r["y"]),
+            math.radians(float(r["yaw_deg"])), int(r["encoder"]), int(r["v2v"]),
+            float(r["front_cm"]) / 100.0, float(r["left_cm"]) / 100.0,
+            float(r["back_cm"]) / 100.0, float(r["right_cm"]) / 100.0, int(r["landmark"])))
+        times.append(float(r["time"]))
+    return pkts, times
+
+
+class RefReplay:
+    """Re-drives dual_bot_mapper.py:826-945 with the imported reference classes."""
+
+    def __init__(self, mapper, size, res, ox, oy, separation):
+        self.m = mapper
+        self.grid = mapper.OccupancyGrid(size, res, ox, oy)
+        self.slam = mapper.PoseGraphSLAM()
+        self.separation = separation
+        self.drift = {1: (0.0, 0.0), 2: (0.0, 0.0)}
+        self.clouds = {b: {k: [] for k in mapper.SENSOR_ANGLES_RAD} for b in (1, 2)}
+        self.paths = {1: ([], []), 2: ([], [])}
+        self.pkt_counts = {1: 0, 2: 0}
+        self.poses = []          # per accepted datagram: (datagram index, agent, rx, ry, ryaw)
+        self.accepted = []       # per datagram: 1/0
+        self.closure_lines = []
+
+    def feed(self, data, now=0.0):
+        m = self.m
+        landmark_type = m.LM_NONE
+        if len(data) == m.PACKET_SIZE:
+            (magic, agent_id, rx, ry, ryaw, enc, v2v,
+             d_front, d_left, d_back, d_right, landmark_type) = struct.unpack(m.PACKET_FMT, data)
+        elif len(data) == m.PACKET_SIZE_V1:
+            (magic, agent_id, rx, ry, ryaw, enc, v2v,
+             d_front, d_left, d_back, d_right) = struct.unpack(m.PACKET_FMT_V1, data)
+            landmark_type = m.LM_NONE
+        else:
+            self.accepted.append(0)
+            return
+        if magic != b"QSRL" or agent_id not in [1, 2]:
+            self.accepted.append(0)
+            return
+        self.accepted.append(1)
+        self.pkt_counts[agent_id] += 1
+        if agent_id == 2:
+            rx += self.separation
+        cdx, cdy = self.drift[agent_id]
+        rx += cdx
+        ry += cdy
+        self.paths[agent_id][0].append(rx)
+        self.paths[agent_id][1].append(ry)
+        self.poses.append((len(self.accepted) - 1, agent_id, rx, ry, ryaw))
+        sensors = {"front": d_front, "left": d_left, "back": d_back, "right": d_right}
+        for name, dist in sensors.items():
+            ray_angle = ryaw + m.SENSOR_ANGLES_RAD[name]
+            hit_valid = m.MIN_DIST_M < dist <= m.MAX_DIST_M
+            if hit_valid:
+                wx = rx + dist * math.cos(ray_angle)
+                wy = ry + dist * math.sin(ray_angle)
+                self.clouds[agent_id][name].append((wx, wy))
+                self.grid.update_ray(rx, ry, wx, wy, True)
+            else:
+                max_range = min(dist, m.MAX_DIST_M) if dist > m.MIN_DIST_M else m.MAX_DIST_M
+                end_x = rx + max_range * math.cos(ray_angle)
+                end_y = ry + max_range * math.sin(ray_angle)
+                self.grid.update_ray(rx, ry, end_x, end_y, False)
+        closure, cdx_new, cdy_new = self.slam.add_pose(rx, ry, ryaw, agent_id, landmark_type, now)
+        if closure:
+            self.drift[agent_id] = (self.drift[agent_id][0] + cdx_new,
+                                    self.drift[agent_id][1] + cdy_new)
+            self.closure_lines.append((rx, ry, rx + cdx_new, ry + cdy_new))
+
+    def zone_of(self, other_id):
+        """dual_bot_mapper.py:930-940: bbox over `other`'s hit points + path."""
+        xs = sum(([p[0] for p in pts] for pts in self.clouds[other_id].values()), []) \
+            + self.paths[other_id][0]
+        ys = sum(([p[1] for p in pts] for pts in self.clouds[other_id].values()), []) \
+            + self.paths[other_id][1]
+        return self.m.compute_bounding_box(xs, ys)
+
+    def zone_bytes(self, box):
+        m = self.m
+        if box is None:
+            return struct.pack(m.ZONE_FMT, b"ZONE", 999.0, 999.0, -999.0, -999.0)
+        return struct.pack(m.ZONE_FMT, b"ZONE", box[0], box[1], box[2], box[3])
+
+
+def pack_stream(datagrams):
+    """Variable-length datagrams -> (flat uint8 [n,48] zero padded, lengths uint16)."""
+    n = len(datagrams)
+    buf = np.zeros((n, 48), dtype=np.uint8)
+    lens = np.zeros(n, dtype=np.uint16)
+    for i, d in enumerate(datagrams):
+        assert len(d) <= 48
+        buf[i, :len(d)] = np.frombuffer(d, dtype=np.uint8)
+        lens[i] = len(d)
+    return buf, lens
+
+
+def scenario_outputs(rep, store_dense):
+    g = rep.grid.grid
+    out = {
+        "accepted": np.array(rep.accepted, dtype=np.uint8),
+        "pose_idx": np.array([p[0] for p in rep.poses], dtype=np.int64),
+        "pose_agent": np.array([p[1] for p in rep.poses], dtype=np.int32),
+        "pose_xyyaw": np.array([[p[2], p[3], p[4]] for p in rep.poses], dtype=np.float64).reshape(-1, 3),
+        "closures_idx": np.array([[c[0], c[1]] for c in rep.slam.closures], dtype=np.int64).reshape(-1, 2),
+        "closures_corr": np.array([[c[2], c[3]] for c in rep.slam.closures], dtype=np.float64).reshape(-1, 2),
+        "landmarks_xy": np.array([[l[0], l[1]] for l in rep.slam.landmarks], dtype=np.float64).reshape(-1, 2),
+        "landmarks_type_idx": np.array([[l[2], l[3]] for l in rep.slam.landmarks], dtype=np.int64).reshape(-1, 2),
+        "drift": np.array([rep.drift[1], rep.drift[2]], dtype=np.float64),
+        "n_nodes": np.array([len(rep.slam.nodes)], dtype=np.int64),
+        "grid_sha256": np.frombuffer(hashlib.sha256(g.tobytes()).digest(), dtype=np.uint8),
+        "grid_counts": np.array([(g == 0).sum(), (g == 100).sum(), (g == -1).sum()], dtype=np.int64),
+    }
+    known = np.argwhere(g != -1)
+    out["grid_known_yx"] = known.astype(np.int32)
+    out["grid_known_val"] = g[known[:, 0], known[:, 1]].astype(np.int8)
+    if store_dense:
+        out["grid"] = g.copy()
+    for b in (1, 2):
+        pts = sum((rep.clouds[b][k] for k in rep.m.SENSOR_ANGLES_RAD), [])
+        out[f"hits_bot{b}"] = np.array(pts, dtype=np.float64).reshape(-1, 2)
+        for k in rep.m.SENSOR_ANGLES_RAD:
+            out[f"hits_bot{b}_{k}"] = np.array(rep.clouds[b][k], dtype=np.float64).reshape(-1, 2)
+        box = rep.zone_of(b)
+        out[f"zone_bot{b}"] = np.array(box if box is not None else [np.nan] * 4, dtype=np.float64)
+        out[f"zone_bytes_bot{b}"] = np.frombuffer(rep.zone_bytes(box), dtype=np.uint8)
+        out[f"path_bot{b}"] = np.array(rep.paths[b], dtype=np.float64).T.reshape(-1, 2)
+    return out
+
+
+def run_scenario(mapper, name, datagrams, size, res, ox, oy, separation, store_dense=True, extra=None):
+    rep = RefReplay(mapper, size, res, ox, oy, separation)
+    for d in datagrams:
+        rep.feed(d)
+    buf, lens = pack_stream(datagrams)
+    out = scenario_outputs(rep, store_dense)
+    out["datagrams"] = buf
+    out["lengths"] = lens
+    out["cfg"] = np.array([size, res, ox, oy, separation], dtype=np.float64)
+    if extra:
+        out.update(extra)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(f"[{name}] n={len(datagrams)} accepted={sum(rep.accepted)} closures={len(rep.slam.closures)} "
+          f"free/occ/unk={out['grid_counts'].tolist()} sha={hashlib.sha256(rep.grid.grid.tobytes()).hexdigest()[:16]}")
+    return rep
+
+
+def adversarial_stream(mapper, n, seed, lo, hi):
+    rng = random.Random(seed)
+    lm_hist = [0] * 555 + [5] * 128 + [3] * 3 + [2] * 1 + [1] * 6 + [4] * 6
+    out = []
+    for i in range(n):
+        d = []
+        for _ in range(4):
+            u = rng.random()
+            if u < 0.03:
+                d.append(0.0)
+            elif u < 0.04:
+                d.append(float("nan"))
+            elif u < 0.05:
+                d.append(float("inf"))
+            elif u < 0.06:
+                d.append(-0.5)
+            elif u < 0.08:
+                d.append(rng.choice([0.05, 1.2, 1.2000000476837158, 0.05000000074505806]))
+            else:
+                d.append(rng.uniform(0.02, 2.5))
+        out.append(struct.pack(
+            mapper.PACKET_FMT, b"QSRL", rng.choice([1, 2]), rng.uniform(lo, hi), rng.uniform(lo, hi),
+            rng.uniform(-math.pi, math.pi), i, rng.randrange(1000), d[0], d[1], d[2], d[3],
+            rng.choice(lm_hist)))
+    return out
+
+
+def main():
+    mapper, gen = load_reference()
+    kat = {}
+
+    # ---- protocol sizes (dual_bot_mapper.py:41-54) ----------------------------------
+    kat["sizes"] = {"v2": mapper.PACKET_SIZE, "v1": mapper.PACKET_SIZE_V1,
+                    "zone": mapper.ZONE_SIZE, "target": mapper.TARGET_SIZE}
+    kat["zone_1234_hex"] = struct.pack(mapper.ZONE_FMT, b"ZONE", 1.0, 2.0, 3.0, 4.0).hex()
+
+    # ---- world_to_grid / grid_to_world KATs (dual_bot_mapper.py:121-131) ------------
+    g200 = mapper.OccupancyGrid()
+    w2g_in = [0.0, -0.01, 0.05, 0.15, -5.049, -5.051, 5.0, 4.999999, -4.95, 0.1, 0.2, 0.3,
+              1.0000001, 2.55, -2.55, 3.3499999940395355, 0.30000001192092896]
+    kat["world_to_grid_200"] = [[w, g200.world_to_grid(w, w)[0]] for w in w2g_in]
+    g4096 = mapper.OccupancyGrid(4096, 0.05, -102.4, -102.4)
+    kat["world_to_grid_4096"] = [[w, g4096.world_to_grid(w, w)[0]] for w in w2g_in]
+    kat["grid_to_world_200"] = [[i, g200.grid_to_world(i, i)[0]] for i in (0, 1, 99, 100, 199)]
+
+    # ---- exhaustive Bresenham table (dual_bot_mapper.py:158-179) ---------------------
+    D = 40
+    starts, cells = [], []
+    pos = 0
+    for dy in range(-D, D + 1):
+        for dx in range(-D, D + 1):
+            c = g200._bresenham(0, 0, dx, dy)
+            starts.append(pos)
+            cells.extend(c)
+            pos += len(c)
+    starts.append(pos)
+    # translation invariance spot check with a non-zero origin
+    assert [(x - 7, y + 3) for x, y in g200._bresenham(7, -3, 12, -1)] == g200._bresenham(0, 0, 5, 2)
+    np.savez_compressed(os.path.join(HERE, "bresenham_d40.npz"),
+                        D=np.array([D]), starts=np.array(starts, dtype=np.int64),
+                        cells=np.array(cells, dtype=np.int8))
+    kat["bresenham_0_0_5_2"] = g200._bresenham(0, 0, 5, 2)
+
+    # ---- single update_ray cases on a 32x32 grid -------------------------------------
+    rng = random.Random(7)
+    cases = []
+    small = dict(size=32, res=0.05, ox=-0.8, oy=-0.8)
+    for i in range(400):
+        span = 1.1 if i % 3 else 0.7
+        rx, ry = rng.uniform(-span, span), rng.uniform(-span, span)
+        hx, hy = rx + rng.uniform(-1.3, 1.3), ry + rng.uniform(-1.3, 1.3)
+        if i % 17 == 0:
+            hx, hy = rx, ry
+        cases.append((rx, ry, hx, hy, i % 2))
+    grids = []
+    for rx, ry, hx, hy, v in cases:
+        g = mapper.OccupancyGrid(small["size"], small["res"], small["ox"], small["oy"])
+        g.update_ray(rx, ry, hx, hy, bool(v))
+        grids.append(g.grid.copy())
+    gseq = mapper.OccupancyGrid(small["size"], small["res"], small["ox"], small["oy"])
+    for rx, ry, hx, hy, v in cases:
+        gseq.update_ray(rx, ry, hx, hy, bool(v))
+    np.savez_compressed(os.path.join(HERE, "update_ray_cases.npz"),
+                        cfg=np.array([small["size"], small["res"], small["ox"], small["oy"]]),
+                        rays=np.array(cases, dtype=np.float64), grids=np.array(grids, dtype=np.int8),
+                        grid_sequential=gseq.grid.copy())
+
+    # ---- the deterministic fake session (generate_fake_dual_session.py, seed 42) ----
+    telem, cloud = run_generator(gen)
+    telem2, _ = run_generator(gen)
+    assert telem == telem2, "generator is not deterministic"
+    with open(os.path.join(HERE, "session_telemetry.csv"), "wb") as f:
+        f.write(telem)
+    pkts, times = telemetry_to_packets(mapper, telem)
+    stream = b"".join(pkts)
+    kat["session"] = {
+        "rows": len(pkts),
+        "telemetry_sha256": hashlib.sha256(telem).hexdigest(),
+        "pointcloud_sha256": hashlib.sha256(cloud).hexdigest(),
+        "pointcloud_rows": len(cloud.decode().splitlines()) - 1,
+        "packets_sha256": hashlib.sha256(stream).hexdigest(),
+    }
+    recv = {"recv_time": np.array(times, dtype=np.float64)}
+
+    rep = run_scenario(mapper, "session_200", pkts, 200, 0.05, -5.0, -5.0, 0.0, extra=recv)
+    kat["session"]["grid200_sha256"] = hashlib.sha256(rep.grid.grid.tobytes()).hexdigest()
+    rep = run_scenario(mapper, "session_512", pkts, 512, 0.05, -12.8, -12.8, 0.0, extra=recv)
+    kat["session"]["grid512_sha256"] = hashlib.sha256(rep.grid.grid.tobytes()).hexdigest()
+    kat["session"]["closures"] = [list(c) for c in rep.slam.closures]
+    kat["session"]["drift"] = {"1": list(rep.drift[1]), "2": list(rep.drift[2])}
+    kat["session"]["zone_bot1"] = list(rep.zone_of(1))
+    kat["session"]["zone_bot1_hex"] = rep.zone_bytes(rep.zone_of(1)).hex()
+    kat["session"]["landmarks"] = len(rep.slam.landmarks)
+    rep = run_scenario(mapper, "session_4096", pkts, 4096, 0.05, -102.4, -102.4, 0.0,
+                       store_dense=False, extra=recv)
+    kat["session"]["grid4096_sha256"] = hashlib.sha256(rep.grid.grid.tobytes()).hexdigest()
+
+    # separation applied to bot 2 (dual_bot_mapper.py:851-852)
+    run_scenario(mapper, "session_sep_512", pkts, 512, 0.05, -12.8, -12.8, 0.5)
+
+    # five laps of the same session: dense loop closures, cool-down logic exercised
+    run_scenario(mapper, "laps5_512", pkts * 5, 512, 0.05, -12.8, -12.8, 0.0)
+
+    # finer resolution: long rays (up to ~100 cells)
+    run_scenario(mapper, "session_fine_1024", pkts, 1024, 0.0125, -6.4, -6.4, 0.0)
+
+    # mixed datagrams: v1 (41 B), bad magic, bad agent ids, wrong lengths, dummy zero packets
+    rng = random.Random(99)
+    mixed = []
+    for i, p in enumerate(pkts[:300]):
+        u = rng.random()
+        if u < 0.10:
+            mixed.append(p[:41])                              # v1 packet: landmark dropped
+        elif u < 0.14:
+            mixed.append(b"QSRX" + p[4:])                     # bad magic
+        elif u < 0.18:
+            mixed.append(p[:4] + bytes([rng.choice([0, 3, 255])]) + p[5:])  # agent not in {1,2}
+        elif u < 0.21:
+            mixed.append(p[:rng.choice([40, 20, 0])])          # short datagram
+        elif u < 0.24:
+            mixed.append(p + b"\x00" * rng.choice([1, 6]))     # long datagram
+        elif u < 0.30:                                        # smartDelay dummy: all distances 0
+            f = list(struct.unpack(mapper.PACKET_FMT, p))
+            f[7:11] = [0.0, 0.0, 0.0, 0.0]
+            mixed.append(struct.pack(mapper.PACKET_FMT, *f))
+        else:
+            mixed.append(p)
+    run_scenario(mapper, "mixed_200", mixed, 200, 0.05, -5.0, -5.0, 0.25)
+
+    # adversarial uniform-random stream, partly out of bounds, odd distances
+    adv = adversarial_stream(mapper, 4000, 1234, -14.0, 14.0)
+    run_scenario(mapper, "adversarial_512", adv, 512, 0.05, -12.8, -12.8, 0.0)
+    adv2 = adversarial_stream(mapper, 3000, 4321, -3.0, 3.0)
+    run_scenario(mapper, "adversarial_dense_200", adv2, 200, 0.05, -5.0, -5.0, 0.0)
+
+    with open(os.path.join(HERE, "kat.json"), "w") as f:
+        json.dump(kat, f, indent=1, sort_keys=True)
+    print(json.dumps(kat["session"], indent=1)[:1500])
+
+
+if __name__ == "__main__":
+    main()
