@@ -1,0 +1,166 @@
+// decode.hip -- K0: QuasarPacket datagrams -> validated SoA batch.
+// Semantics: server_nodes/dual_bot_mapper.py:826-857 (unpack, length/magic/agent filters,
+// bot-2 offset).  The drift correction of :855-857 is applied by the SLAM stage because it
+// depends on earlier loop closures.
+#include "qs_internal.h"
+
+#define DEC_BLOCK 256
+#define DEC_MAX_STRIDE 64   // records are staged through LDS when stride <= 64 bytes
+
+// One workgroup stages DEC_BLOCK consecutive records (DEC_BLOCK*stride contiguous bytes) into
+// LDS with coalesced dword loads, then each lane parses its own record from LDS: the 42-byte
+// packed layout puts every float at an odd offset, so a direct per-lane global read would be
+// ten unaligned loads per lane.
+__global__ void __launch_bounds__(DEC_BLOCK)
+qs_decode_kernel(const unsigned char *__restrict__ pkts, size_t n, size_t stride,
+                 const unsigned short *__restrict__ lens, const double *__restrict__ offset,
+                 int max_agent, int bots_per_graph, int n_graphs, QsBatch b,
+                 unsigned long long *__restrict__ graph_batch,
+                 unsigned long long *__restrict__ counters)
+{
+    __shared__ unsigned int s_raw[DEC_BLOCK * DEC_MAX_STRIDE / 4 + 2];
+    __shared__ unsigned int s_acc, s_hist_small[64][2];
+    const size_t base = (size_t)blockIdx.x * DEC_BLOCK;
+    const int tid = threadIdx.x;
+    const size_t nrec = (n - base < DEC_BLOCK) ? (n - base) : DEC_BLOCK;
+    const bool small_g = n_graphs <= 64;
+
+    if (tid == 0) s_acc = 0;
+    if (small_g && tid < 64) { s_hist_small[tid][0] = 0; s_hist_small[tid][1] = 0; }
+
+    // stage: the byte range [base*stride, (base+nrec)*stride) widened to dword boundaries
+    const size_t byte0 = base * stride;
+    const size_t byte1 = byte0 + nrec * stride;
+    const size_t total = n * stride;
+    const unsigned long long addr0 = (unsigned long long)pkts + byte0;
+    const unsigned int mis = (unsigned int)(addr0 & 3);          // misalignment of the range
+    const unsigned int *src = (const unsigned int *)(addr0 - mis);
+    const size_t ndw = (mis + (byte1 - byte0) + 3) / 4;
+    // the last dword may reach past the caller's buffer by <4 bytes: read it bytewise
+    const unsigned long long buf_end = (unsigned long long)pkts + total;
+    for (size_t k = tid; k < ndw; k += DEC_BLOCK) {
+        const unsigned long long a = (unsigned long long)(src + k);
+        unsigned int v;
+        if (a + 4 <= buf_end && a >= (unsigned long long)pkts) {
+            v = src[k];
+        } else {
+            v = 0;
+            const unsigned char *p = (const unsigned char *)a;
+            for (int q = 0; q < 4; q++)
+                if (a + q >= (unsigned long long)pkts && a + q < buf_end) v |= (unsigned int)p[q] << (8 * q);
+        }
+        s_raw[k] = v;
+    }
+    __syncthreads();
+
+    bool ok = false;
+    int agent = 0, lmk = 0;
+    if ((size_t)tid < nrec) {
+        const size_t i = base + tid;
+        const unsigned char *r = (const unsigned char *)s_raw + mis + (size_t)tid * stride;
+        const int len = lens ? (int)lens[i] : (int)stride;
+        // :826-838 version by length
+        if ((len == QS_PACKET_SIZE || len == QS_PACKET_SIZE_V1) && (size_t)len <= stride) {
+            unsigned char f[QS_PACKET_SIZE];
+            #pragma unroll
+            for (int q = 0; q < QS_PACKET_SIZE; q++) f[q] = r[q < len ? q : 0];
+            agent = f[4];
+            lmk = (len == QS_PACKET_SIZE) ? f[41] : 0;
+            float x, y, yaw, d0, d1, d2, d3; int enc;
+            __builtin_memcpy(&x, f + 5, 4);  __builtin_memcpy(&y, f + 9, 4);
+            __builtin_memcpy(&yaw, f + 13, 4); __builtin_memcpy(&enc, f + 17, 4);
+            __builtin_memcpy(&d0, f + 25, 4); __builtin_memcpy(&d1, f + 29, 4);
+            __builtin_memcpy(&d2, f + 33, 4); __builtin_memcpy(&d3, f + 37, 4);
+            ok = f[0] == 'Q' && f[1] == 'S' && f[2] == 'R' && f[3] == 'L'      // :840
+                 && agent >= 1 && agent <= max_agent;                           // :842
+            // CPython's int() raises on a non-finite pose (:123); the build drops the packet
+            ok = ok && isfinite(x) && isfinite(y) && isfinite(yaw);
+            if (ok) {
+                b.agent[i] = (unsigned char)agent;
+                b.lm[i] = (unsigned char)lmk;
+                b.px[i] = (double)x + offset[agent];                            // :851-852
+                b.py[i] = (double)y;
+                b.yaw[i] = (double)yaw;
+                b.dist[i] = make_float4(d0, d1, d2, d3);
+                b.enc[i] = enc;
+            }
+        }
+        b.accept[i] = ok ? 1 : 0;
+    }
+    // per-graph accepted / landmark-event counts of the batch (capacity planning + counters)
+    if (ok) {
+        const int g = (agent - 1) / bots_per_graph;
+        if (small_g) {
+            atomicAdd(&s_hist_small[g][0], 1u);
+            if (lmk) atomicAdd(&s_hist_small[g][1], 1u);
+        } else {
+            atomicAdd(&graph_batch[2 * g], 1ull);
+            if (lmk) atomicAdd(&graph_batch[2 * g + 1], 1ull);
+        }
+        atomicAdd(&s_acc, 1u);
+    }
+    __syncthreads();
+    if (small_g && tid < n_graphs) {
+        if (s_hist_small[tid][0]) atomicAdd(&graph_batch[2 * tid], (unsigned long long)s_hist_small[tid][0]);
+        if (s_hist_small[tid][1]) atomicAdd(&graph_batch[2 * tid + 1], (unsigned long long)s_hist_small[tid][1]);
+    }
+    if (tid == 0) {
+        atomicAdd(&counters[QS_CNT_DATAGRAMS], (unsigned long long)nrec);
+        if (s_acc) atomicAdd(&counters[QS_CNT_ACCEPTED], (unsigned long long)s_acc);
+    }
+}
+
+// Fallback for strides the LDS stage does not cover (> 64 bytes): per-lane byte reads.
+__global__ void __launch_bounds__(DEC_BLOCK)
+qs_decode_wide_kernel(const unsigned char *__restrict__ pkts, size_t n, size_t stride,
+                      const unsigned short *__restrict__ lens, const double *__restrict__ offset,
+                      int max_agent, int bots_per_graph, QsBatch b,
+                      unsigned long long *__restrict__ graph_batch,
+                      unsigned long long *__restrict__ counters)
+{
+    const size_t i = (size_t)blockIdx.x * DEC_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const unsigned char *r = pkts + i * stride;
+    const int len = lens ? (int)lens[i] : (int)stride;
+    bool ok = false;
+    if ((len == QS_PACKET_SIZE || len == QS_PACKET_SIZE_V1) && (size_t)len <= stride) {
+        unsigned char f[QS_PACKET_SIZE];
+        for (int q = 0; q < QS_PACKET_SIZE; q++) f[q] = r[q < len ? q : 0];
+        const int agent = f[4];
+        const int lmk = (len == QS_PACKET_SIZE) ? f[41] : 0;
+        float x, y, yaw, d0, d1, d2, d3; int enc;
+        __builtin_memcpy(&x, f + 5, 4);  __builtin_memcpy(&y, f + 9, 4);
+        __builtin_memcpy(&yaw, f + 13, 4); __builtin_memcpy(&enc, f + 17, 4);
+        __builtin_memcpy(&d0, f + 25, 4); __builtin_memcpy(&d1, f + 29, 4);
+        __builtin_memcpy(&d2, f + 33, 4); __builtin_memcpy(&d3, f + 37, 4);
+        ok = f[0] == 'Q' && f[1] == 'S' && f[2] == 'R' && f[3] == 'L' && agent >= 1 &&
+             agent <= max_agent && isfinite(x) && isfinite(y) && isfinite(yaw);
+        if (ok) {
+            b.agent[i] = (unsigned char)agent; b.lm[i] = (unsigned char)lmk;
+            b.px[i] = (double)x + offset[agent]; b.py[i] = (double)y; b.yaw[i] = (double)yaw;
+            b.dist[i] = make_float4(d0, d1, d2, d3); b.enc[i] = enc;
+            const int g = (agent - 1) / bots_per_graph;
+            atomicAdd(&graph_batch[2 * g], 1ull);
+            if (lmk) atomicAdd(&graph_batch[2 * g + 1], 1ull);
+            atomicAdd(&counters[QS_CNT_ACCEPTED], 1ull);
+        }
+    }
+    b.accept[i] = ok ? 1 : 0;
+    atomicAdd(&counters[QS_CNT_DATAGRAMS], 1ull);
+}
+
+hipError_t qs_launch_decode(qs_ctx *c, const unsigned char *d_pkts, size_t n, size_t stride,
+                            const unsigned short *d_lens)
+{
+    if (n == 0) return hipSuccess;
+    const unsigned int blocks = (unsigned int)((n + DEC_BLOCK - 1) / DEC_BLOCK);
+    if (stride <= DEC_MAX_STRIDE)
+        hipLaunchKernelGGL(qs_decode_kernel, dim3(blocks), dim3(DEC_BLOCK), 0, c->stream, d_pkts, n,
+                           stride, d_lens, c->d_offset, c->cfg.max_agent, c->bots_per_graph,
+                           c->n_graphs, c->b, c->d_graph_batch, c->d_counters);
+    else
+        hipLaunchKernelGGL(qs_decode_wide_kernel, dim3(blocks), dim3(DEC_BLOCK), 0, c->stream, d_pkts,
+                           n, stride, d_lens, c->d_offset, c->cfg.max_agent, c->bots_per_graph, c->b,
+                           c->d_graph_batch, c->d_counters);
+    return hipGetLastError();
+}

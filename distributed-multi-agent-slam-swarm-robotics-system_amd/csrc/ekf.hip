@@ -1,0 +1,211 @@
+// ekf.hip -- K5: the firmware's 6-state EKF, batched per bot.
+// Semantics: AgentFirmware_Bot1/ekf.cpp:5-92 (state layout ekf.h:38-44):
+//   x = [x, y, theta, v, omega, bias_omega], P0 = I, Q = diag(.01,.01,.01,.1,.1,.001),
+//   R = diag(.05,.05); predict() on the gyro rate, update() on the encoder [v, omega].
+// The Jacobian is the identity plus seven entries, so J P J^T and (I - K H) P are evaluated
+// row/column-sparse; every kept term is summed in the same (ascending-k) order as a dense
+// triple loop, so the result equals the dense product exactly (the dropped terms are +-0).
+//
+// The mapper never uses the EKF pose (dual_bot_mapper.py:829-831 takes the packet pose; the
+// firmware itself runs the filter "for internal state estimation", AgentFirmware_Bot1.ino:
+// 697-707), so this stage is telemetry: it must not feed the raycast.
+#include "qs_internal.h"
+
+#define EKF_STRIDE 44   // x[6], P[36], last_time, initialized
+#define EKF_PI 3.14159265358979323846
+
+struct EkfState { double x[6]; double P[36]; double last_t; double init; };
+
+__device__ inline void ekf_load(const double *f, EkfState &s)
+{
+    #pragma unroll
+    for (int i = 0; i < 6; i++) s.x[i] = f[i];
+    #pragma unroll
+    for (int i = 0; i < 36; i++) s.P[i] = f[6 + i];
+    s.last_t = f[42]; s.init = f[43];
+}
+__device__ inline void ekf_store(double *f, const EkfState &s)
+{
+    #pragma unroll
+    for (int i = 0; i < 6; i++) f[i] = s.x[i];
+    #pragma unroll
+    for (int i = 0; i < 36; i++) f[6 + i] = s.P[i];
+    f[42] = s.last_t; f[43] = s.init;
+}
+__device__ inline void ekf_init(EkfState &s, double t, const double x0[6])   // ekf.cpp:5-19
+{
+    #pragma unroll
+    for (int i = 0; i < 6; i++) s.x[i] = x0[i];
+    #pragma unroll
+    for (int r = 0; r < 6; r++)
+        #pragma unroll
+        for (int c = 0; c < 6; c++) s.P[6 * r + c] = (r == c) ? 1.0 : 0.0;
+    s.last_t = t; s.init = 1.0;
+}
+
+__device__ inline void ekf_predict(EkfState &s, double omega_measured, double t)   // ekf.cpp:26-68
+{
+    if (s.init == 0.0) return;
+    const double dt = t - s.last_t;
+    if (!(dt > 0)) return;                                // `if (dt <= 0) return;` (NaN: skip too)
+    s.last_t = t;
+    const double theta = s.x[2], v = s.x[3], bias = s.x[5];
+    const double omega_c = omega_measured - bias;
+    double theta_new = theta + omega_c * dt;
+    if (theta_new > EKF_PI) theta_new -= 2 * EKF_PI;
+    else if (theta_new < -EKF_PI) theta_new += 2 * EKF_PI;
+    const double ct = cos(theta), st = sin(theta);
+    const double x_new = s.x[0] + v * ct * dt;
+    const double y_new = s.x[1] + v * st * dt;
+    s.x[0] = x_new; s.x[1] = y_new; s.x[2] = theta_new; s.x[4] = omega_c;
+    const double j02 = -v * st * dt, j03 = ct * dt, j12 = v * ct * dt, j13 = st * dt, j25 = -dt;
+    double JP[36];
+    #pragma unroll
+    for (int c = 0; c < 6; c++) {
+        JP[0 * 6 + c] = (s.P[0 * 6 + c] + j02 * s.P[2 * 6 + c]) + j03 * s.P[3 * 6 + c];
+        JP[1 * 6 + c] = (s.P[1 * 6 + c] + j12 * s.P[2 * 6 + c]) + j13 * s.P[3 * 6 + c];
+        JP[2 * 6 + c] = s.P[2 * 6 + c] + j25 * s.P[5 * 6 + c];
+        JP[3 * 6 + c] = s.P[3 * 6 + c];
+        JP[4 * 6 + c] = -1.0 * s.P[5 * 6 + c];            // J(omega,omega) = 0, J(omega,bias) = -1
+        JP[5 * 6 + c] = s.P[5 * 6 + c];
+    }
+    const double Q[6] = {0.01, 0.01, 0.01, 0.1, 0.1, 0.001};                            // ekf.cpp:11
+    #pragma unroll
+    for (int r = 0; r < 6; r++) {
+        const double a0 = (JP[6 * r + 0] + JP[6 * r + 2] * j02) + JP[6 * r + 3] * j03;
+        const double a1 = (JP[6 * r + 1] + JP[6 * r + 2] * j12) + JP[6 * r + 3] * j13;
+        const double a2 = JP[6 * r + 2] + JP[6 * r + 5] * j25;
+        const double a3 = JP[6 * r + 3];
+        const double a4 = JP[6 * r + 5] * -1.0;
+        const double a5 = JP[6 * r + 5];
+        s.P[6 * r + 0] = a0 + (r == 0 ? Q[0] : 0.0);
+        s.P[6 * r + 1] = a1 + (r == 1 ? Q[1] : 0.0);
+        s.P[6 * r + 2] = a2 + (r == 2 ? Q[2] : 0.0);
+        s.P[6 * r + 3] = a3 + (r == 3 ? Q[3] : 0.0);
+        s.P[6 * r + 4] = a4 + (r == 4 ? Q[4] : 0.0);
+        s.P[6 * r + 5] = a5 + (r == 5 ? Q[5] : 0.0);
+    }
+}
+
+__device__ inline void ekf_update(EkfState &s, double z_v, double z_omega)   // ekf.cpp:70-92
+{
+    if (s.init == 0.0) return;
+    const double R0 = 0.05, R1 = 0.05;                                                  // ekf.cpp:12
+    const double y0 = z_v - s.x[3], y1 = z_omega - s.x[4];
+    const double s00 = s.P[3 * 6 + 3] + R0, s01 = s.P[3 * 6 + 4];
+    const double s10 = s.P[4 * 6 + 3], s11 = s.P[4 * 6 + 4] + R1;
+    const double det = s00 * s11 - s01 * s10;
+    const double i00 = s11 / det, i01 = -s01 / det, i10 = -s10 / det, i11 = s00 / det;
+    double K0[6], K1[6];
+    #pragma unroll
+    for (int r = 0; r < 6; r++) {
+        const double p3 = s.P[6 * r + 3], p4 = s.P[6 * r + 4];
+        K0[r] = p3 * i00 + p4 * i10;
+        K1[r] = p3 * i01 + p4 * i11;
+    }
+    #pragma unroll
+    for (int r = 0; r < 6; r++) s.x[r] = s.x[r] + (K0[r] * y0 + K1[r] * y1);
+    double P3[6], P4[6];
+    #pragma unroll
+    for (int c = 0; c < 6; c++) { P3[c] = s.P[3 * 6 + c]; P4[c] = s.P[4 * 6 + c]; }
+    #pragma unroll
+    for (int c = 0; c < 6; c++) {
+        // (I - K H) P, rows in ascending k: k = r term, then k = 3, then k = 4 (r < 3);
+        // k = 3, k = 4, then k = 5 (r = 5); rows 3 and 4 carry (1 - K) on their own column.
+        const double n0 = (s.P[0 * 6 + c] + (-K0[0]) * P3[c]) + (-K1[0]) * P4[c];
+        const double n1 = (s.P[1 * 6 + c] + (-K0[1]) * P3[c]) + (-K1[1]) * P4[c];
+        const double n2 = (s.P[2 * 6 + c] + (-K0[2]) * P3[c]) + (-K1[2]) * P4[c];
+        const double n3 = (1.0 - K0[3]) * P3[c] + (-K1[3]) * P4[c];
+        const double n4 = (-K0[4]) * P3[c] + (1.0 - K1[4]) * P4[c];
+        const double n5 = ((-K0[5]) * P3[c] + (-K1[5]) * P4[c]) + s.P[5 * 6 + c];
+        s.P[0 * 6 + c] = n0; s.P[1 * 6 + c] = n1; s.P[2 * 6 + c] = n2;
+        s.P[3 * 6 + c] = n3; s.P[4 * 6 + c] = n4; s.P[5 * 6 + c] = n5;
+    }
+}
+
+// ---- ingest wiring (build-defined; modelled on esp32_firmware/src/main.cpp:176-188) --------
+// Per accepted packet of a bot, in arrival order: first packet initialises the filter at the
+// packet pose; later packets derive omega_m = wrap(yaw - yaw_prev)/dt and
+// v_enc = (enc - enc_prev) * metres_per_tick / dt, then predict(omega_m, t); update(v_enc, omega_m).
+// One wave per bot: the wave scans the batch 64 records at a time (coalesced), ballots the
+// records of its bot and steps through them in order; the filter state is wave-uniform.
+#define EKF_BLOCK 256
+__global__ void __launch_bounds__(EKF_BLOCK)
+qs_ekf_ingest_kernel(size_t n, QsBatch b, const double *__restrict__ recv_time, double t_nominal0,
+                     double *__restrict__ ekf, double *__restrict__ prev, int max_agent, double metres_per_tick)
+{
+    const int lane = threadIdx.x & 63;
+    const int bot = blockIdx.x * (EKF_BLOCK / QS_WAVE) + (threadIdx.x >> 6) + 1;
+    if (bot > max_agent) return;
+    EkfState s;
+    ekf_load(ekf + (size_t)bot * EKF_STRIDE, s);
+    double pt = prev[4 * bot], pyaw = prev[4 * bot + 1], penc = prev[4 * bot + 2], seen = prev[4 * bot + 3];
+    for (size_t base = 0; base < n; base += QS_WAVE) {
+        const size_t i = base + lane;
+        const bool mine = i < n && b.accept[i] && b.agent[i] == bot;
+        unsigned long long m = __ballot(mine);
+        while (m) {
+            const int j = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const size_t p = base + j;
+            const double t = recv_time ? recv_time[p] : t_nominal0 + (double)p;
+            const double x = b.px[p], y = b.py[p], yaw = b.yaw[p], enc = (double)b.enc[p];
+            if (seen == 0.0) {
+                const double x0[6] = {x, y, yaw, 0, 0, 0};
+                ekf_init(s, t, x0);
+            } else {
+                const double dt = t - pt;
+                if (dt > 0) {
+                    double dyaw = yaw - pyaw;
+                    if (dyaw > EKF_PI) dyaw -= 2 * EKF_PI;
+                    else if (dyaw < -EKF_PI) dyaw += 2 * EKF_PI;
+                    const double omega_m = dyaw / dt;
+                    const double v_enc = (enc - penc) * metres_per_tick / dt;
+                    ekf_predict(s, omega_m, t);
+                    ekf_update(s, v_enc, omega_m);
+                }
+            }
+            pt = t; pyaw = yaw; penc = enc; seen = 1.0;
+        }
+    }
+    if (lane == 0) {
+        ekf_store(ekf + (size_t)bot * EKF_STRIDE, s);
+        prev[4 * bot] = pt; prev[4 * bot + 1] = pyaw; prev[4 * bot + 2] = penc; prev[4 * bot + 3] = seen;
+    }
+}
+
+hipError_t qs_launch_ekf_ingest(qs_ctx *c, size_t n, const double *d_time)
+{
+    if (n == 0) return hipSuccess;
+    const int waves = EKF_BLOCK / QS_WAVE;
+    hipLaunchKernelGGL(qs_ekf_ingest_kernel, dim3((c->cfg.max_agent + waves - 1) / waves), dim3(EKF_BLOCK), 0,
+                       c->stream, n, c->b, d_time, (double)c->next_seq, c->d_ekf, c->d_ekf_prev, c->cfg.max_agent,
+                       c->cfg.ekf_metres_per_tick);
+    return hipGetLastError();
+}
+
+// ---- batched object API: one predict (+ update) per listed bot -----------------------------
+__global__ void qs_ekf_step_kernel(const int *__restrict__ bots, const double *__restrict__ omega,
+                                   const double *__restrict__ t, const double *__restrict__ zv,
+                                   const double *__restrict__ zo, size_t n, int do_update, int max_agent,
+                                   double *__restrict__ ekf)
+{
+    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int bot = bots[k];
+    if (bot < 1 || bot > max_agent) return;
+    EkfState s;
+    ekf_load(ekf + (size_t)bot * EKF_STRIDE, s);
+    ekf_predict(s, omega[k], t[k]);
+    if (do_update) ekf_update(s, zv[k], zo[k]);
+    ekf_store(ekf + (size_t)bot * EKF_STRIDE, s);
+}
+
+hipError_t qs_launch_ekf_step(qs_ctx *c, const int *d_bots, const double *d_omega, const double *d_t,
+                              const double *d_zv, const double *d_zo, size_t n, int do_update)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(qs_ekf_step_kernel, dim3((unsigned int)((n + 63) / 64)), dim3(64), 0, c->stream, d_bots,
+                       d_omega, d_t, d_zv, d_zo, n, do_update, c->cfg.max_agent, c->d_ekf);
+    return hipGetLastError();
+}

@@ -1,0 +1,835 @@
+// qs_api.hip -- the C ABI of include/quasar_slam.h: context, device memory, and the per-batch
+// pipeline  decode (K0) -> SLAM drift (K4) -> raycast (K1) [-> EKF (K5)]  on one HIP stream.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "qs_internal.h"
+
+static thread_local std::string g_create_err;
+
+static int qs_fail(qs_ctx *c, int code, const char *what, hipError_t e = hipSuccess)
+{
+    char buf[512];
+    if (e != hipSuccess) snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+    else snprintf(buf, sizeof buf, "%s", what);
+    if (c) c->err = buf; else g_create_err = buf;
+    return code;
+}
+#define HIPCHK(c, x) do { hipError_t e__ = (x); if (e__ != hipSuccess) return qs_fail((c), QS_E_HIP, #x, e__); } while (0)
+#define ARGCHK(c, cond) do { if (!(cond)) return qs_fail((c), QS_E_INVAL, "invalid argument: " #cond); } while (0)
+
+template <typename T>
+static hipError_t dev_realloc(T **p, size_t count)
+{
+    if (*p) { hipError_t e = hipFree(*p); *p = nullptr; if (e != hipSuccess) return e; }
+    if (count == 0) return hipSuccess;
+    return hipMalloc((void **)p, count * sizeof(T));
+}
+
+extern "C" const char *qs_version(void) { return "quasar-slam-amd 0.1 (gfx950)"; }
+
+extern "C" int qs_config_default(qs_config *cfg)
+{
+    if (!cfg) return QS_E_INVAL;
+    memset(cfg, 0, sizeof *cfg);
+    cfg->size = 200; cfg->res = 0.05; cfg->ox = -5.0; cfg->oy = -5.0;      // dual_bot_mapper.py:87-90
+    cfg->separation = 0.0;                                                  // :715
+    cfg->min_dist = 0.05; cfg->max_dist = 1.20;                             // :57-58
+    cfg->closure_radius = 0.60; cfg->min_poses_between = 30; cfg->closure_correction = 0.5;  // :97-99
+    cfg->max_agent = 2;                                                     // :842
+    cfg->bots_per_graph = 0;
+    cfg->enable_counts = 1;
+    cfg->enable_ekf = 0;
+    cfg->ekf_metres_per_tick = 0.0107;        // simulation_tools/generate_fake_dual_session.py:462
+    cfg->device = 0;
+    cfg->raycast_mode = 0;
+    return QS_OK;
+}
+
+// smallest double T with sqrt(T) >= radius: (s < T) <=> (sqrt(s) < radius) for correctly rounded sqrt
+static double r2_threshold_for(double radius)
+{
+    if (!(radius > 0)) return 0.0;
+    double t = radius * radius;
+    while (sqrt(t) >= radius) t = nextafter(t, 0.0);
+    while (sqrt(t) < radius) t = nextafter(t, INFINITY);
+    return t;
+}
+
+static void graph_free(QsGraphDev &g)
+{
+    hipFree(g.lm_x); hipFree(g.lm_y); hipFree(g.lm_idx); hipFree(g.lm_type);
+    hipFree(g.cl_lm_idx); hipFree(g.cl_node_idx); hipFree(g.cl_dx); hipFree(g.cl_dy);
+    memset(&g, 0, sizeof g);
+}
+
+template <typename T>
+static hipError_t grow_array(T **p, long long old_n, long long new_cap, hipStream_t st)
+{
+    T *q = nullptr;
+    hipError_t e = hipMalloc((void **)&q, (size_t)new_cap * sizeof(T));
+    if (e != hipSuccess) return e;
+    if (*p && old_n > 0) {
+        e = hipMemcpyAsync(q, *p, (size_t)old_n * sizeof(T), hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) return e;
+        e = hipStreamSynchronize(st);
+        if (e != hipSuccess) return e;
+    }
+    if (*p) hipFree(*p);
+    *p = q;
+    return hipSuccess;
+}
+
+static int graph_reserve(qs_ctx *c, int g, long long need_lms, long long need_cls, long long have_lms,
+                         long long have_cls)
+{
+    QsGraphDev &G = c->h_graphs[g];
+    bool changed = false;
+    if (need_lms > G.cap_lms) {
+        long long cap = G.cap_lms ? G.cap_lms : 1024;
+        while (cap < need_lms) cap *= 2;
+        HIPCHK(c, grow_array(&G.lm_x, have_lms, cap, c->stream));
+        HIPCHK(c, grow_array(&G.lm_y, have_lms, cap, c->stream));
+        HIPCHK(c, grow_array(&G.lm_idx, have_lms, cap, c->stream));
+        HIPCHK(c, grow_array(&G.lm_type, have_lms, cap, c->stream));
+        G.cap_lms = cap; changed = true;
+    }
+    if (need_cls > G.cap_cls) {
+        long long cap = G.cap_cls ? G.cap_cls : 256;
+        while (cap < need_cls) cap *= 2;
+        HIPCHK(c, grow_array(&G.cl_lm_idx, have_cls, cap, c->stream));
+        HIPCHK(c, grow_array(&G.cl_node_idx, have_cls, cap, c->stream));
+        HIPCHK(c, grow_array(&G.cl_dx, have_cls, cap, c->stream));
+        HIPCHK(c, grow_array(&G.cl_dy, have_cls, cap, c->stream));
+        G.cap_cls = cap; changed = true;
+    }
+    if (changed) {
+        // pointers and capacities change; the counters n_* live on the device and are preserved
+        QsGraphDev cur;
+        HIPCHK(c, hipMemcpyAsync(&cur, c->d_graphs + g, sizeof cur, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        QsGraphDev upd = G;
+        upd.n_nodes = cur.n_nodes; upd.n_lms = cur.n_lms; upd.n_cls = cur.n_cls;
+        HIPCHK(c, hipMemcpyAsync(c->d_graphs + g, &upd, sizeof upd, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return QS_OK;
+}
+
+static int reset_state(qs_ctx *c)
+{
+    const int nb = c->cfg.max_agent + 1;
+    HIPCHK(c, hipMemsetAsync(c->d_stamps, 0, c->cells * sizeof(unsigned int), c->stream));
+    if (c->d_counts) HIPCHK(c, hipMemsetAsync(c->d_counts, 0, c->cells * sizeof(unsigned long long), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_drift, 0, (size_t)nb * 2 * sizeof(double), c->stream));
+    std::vector<long long> lc(nb, -(long long)c->cfg.min_poses_between);        // :271
+    HIPCHK(c, hipMemcpyAsync(c->d_last_closure, lc.data(), nb * sizeof(long long), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, qs_launch_fill_zone_identity(c));
+    HIPCHK(c, hipMemsetAsync(c->d_counters, 0, QS_CNT_N * sizeof(unsigned long long), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_graph_batch, 0, (size_t)c->n_graphs * 2 * sizeof(unsigned long long), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_ekf, 0, (size_t)nb * 44 * sizeof(double), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_ekf_prev, 0, (size_t)nb * 4 * sizeof(double), c->stream));
+    std::vector<QsGraphDev> upd(c->h_graphs);
+    for (int g = 0; g < c->n_graphs; g++) {
+        upd[g].n_nodes = upd[g].n_lms = upd[g].n_cls = 0;
+        c->lms_upper[g] = 0; c->cls_upper[g] = 0;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_graphs, upd.data(), upd.size() * sizeof(QsGraphDev), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));   // lc / upd are host temporaries
+    c->next_seq = 0; c->epoch_base = 0; c->last_n = 0; c->last_has_poses = false; c->n_rebases = 0;
+    return QS_OK;
+}
+
+extern "C" int qs_create(const qs_config *cfg, qs_ctx **out)
+{
+    if (!cfg || !out) return qs_fail(nullptr, QS_E_INVAL, "qs_create: null argument");
+    *out = nullptr;
+    if (cfg->size < 4 || cfg->size % 4 != 0 || cfg->size > 32768)
+        return qs_fail(nullptr, QS_E_INVAL, "qs_create: size must be a multiple of 4 in [4, 32768]");
+    if (!(cfg->res > 0) || !isfinite(cfg->ox) || !isfinite(cfg->oy))
+        return qs_fail(nullptr, QS_E_INVAL, "qs_create: bad resolution/origin");
+    if (cfg->max_agent < 1 || cfg->max_agent > QS_MAX_AGENT)
+        return qs_fail(nullptr, QS_E_INVAL, "qs_create: max_agent must be in [1, 255]");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return qs_fail(nullptr, QS_E_NODEV, "qs_create: no HIP device (this library has no CPU fallback)");
+    if (cfg->device < 0 || cfg->device >= ndev) return qs_fail(nullptr, QS_E_NODEV, "qs_create: bad device ordinal");
+
+    qs_ctx *c = new qs_ctx();
+    c->cfg = *cfg;
+    c->device = cfg->device;
+    c->bots_per_graph = cfg->bots_per_graph > 0 ? cfg->bots_per_graph : cfg->max_agent;
+    c->n_graphs = (cfg->max_agent + c->bots_per_graph - 1) / c->bots_per_graph;
+    c->win = cfg->min_poses_between < 1 ? 1 : (cfg->min_poses_between > QS_WIN_MAX ? QS_WIN_MAX : cfg->min_poses_between);
+    c->r2_threshold = r2_threshold_for(cfg->closure_radius);
+    c->cells = (size_t)cfg->size * cfg->size;
+    c->geom = QsGeom{cfg->size, cfg->res, cfg->ox, cfg->oy, cfg->min_dist, cfg->max_dist};
+    const int nb = cfg->max_agent + 1;
+#define CREATE_CHK(x) do { hipError_t e__ = (x); if (e__ != hipSuccess) { int rc__ = qs_fail(nullptr, QS_E_HIP, #x, e__); qs_destroy(c); return rc__; } } while (0)
+    CREATE_CHK(hipSetDevice(c->device));
+    CREATE_CHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->own_stream = true;
+    CREATE_CHK(hipMalloc((void **)&c->d_stamps, c->cells * sizeof(unsigned int)));
+    if (cfg->enable_counts) CREATE_CHK(hipMalloc((void **)&c->d_counts, c->cells * sizeof(unsigned long long)));
+    CREATE_CHK(hipMalloc((void **)&c->d_offset, nb * sizeof(double)));
+    CREATE_CHK(hipMalloc((void **)&c->d_drift, nb * 2 * sizeof(double)));
+    CREATE_CHK(hipMalloc((void **)&c->d_last_closure, nb * sizeof(long long)));
+    CREATE_CHK(hipMalloc((void **)&c->d_zone, nb * 4 * sizeof(unsigned long long)));
+    CREATE_CHK(hipMalloc((void **)&c->d_counters, QS_CNT_N * sizeof(unsigned long long)));
+    CREATE_CHK(hipMalloc((void **)&c->d_graph_batch, (size_t)c->n_graphs * 2 * sizeof(unsigned long long)));
+    CREATE_CHK(hipMalloc((void **)&c->d_ekf, (size_t)nb * 44 * sizeof(double)));
+    CREATE_CHK(hipMalloc((void **)&c->d_ekf_prev, (size_t)nb * 4 * sizeof(double)));
+    CREATE_CHK(hipMalloc((void **)&c->d_graphs, (size_t)c->n_graphs * sizeof(QsGraphDev)));
+    CREATE_CHK(hipMemset(c->d_graphs, 0, (size_t)c->n_graphs * sizeof(QsGraphDev)));
+    c->h_graphs.assign(c->n_graphs, QsGraphDev{});
+    c->lms_upper.assign(c->n_graphs, 0);
+    c->cls_upper.assign(c->n_graphs, 0);
+    std::vector<double> off(nb, 0.0);
+    if (cfg->max_agent >= 2) off[2] = cfg->separation;                       // :851-852
+    CREATE_CHK(hipMemcpy(c->d_offset, off.data(), nb * sizeof(double), hipMemcpyHostToDevice));
+#undef CREATE_CHK
+    for (int g = 0; g < c->n_graphs; g++) {
+        int rc = graph_reserve(c, g, 1024, 256, 0, 0);
+        if (rc != QS_OK) { g_create_err = c->err; qs_destroy(c); return rc; }
+    }
+    int rc = reset_state(c);
+    if (rc != QS_OK) { g_create_err = c->err; qs_destroy(c); return rc; }
+    *out = c;
+    return QS_OK;
+}
+
+static void free_batch(qs_ctx *c)
+{
+    QsBatch &b = c->b;
+    hipFree(b.accept); hipFree(b.agent); hipFree(b.lm); hipFree(b.px); hipFree(b.py); hipFree(b.yaw);
+    hipFree(b.dist); hipFree(b.enc); hipFree(b.rx); hipFree(b.ry); hipFree(b.hit); hipFree(b.hit_valid);
+    memset(&b, 0, sizeof b);
+    c->cap_batch = 0;
+}
+
+extern "C" int qs_destroy(qs_ctx *c)
+{
+    if (!c) return QS_OK;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    for (auto &g : c->h_graphs) graph_free(g);
+    free_batch(c);
+    hipFree(c->d_stamps); hipFree(c->d_counts); hipFree(c->d_offset); hipFree(c->d_drift);
+    hipFree(c->d_last_closure); hipFree(c->d_zone); hipFree(c->d_counters); hipFree(c->d_graph_batch);
+    hipFree(c->d_ekf); hipFree(c->d_ekf_prev); hipFree(c->d_graphs); hipFree(c->d_pkts); hipFree(c->d_lens);
+    hipFree(c->d_time); hipFree(c->d_bin_ws);
+    for (auto &p : c->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
+    for (auto e : c->ev_pool) hipEventDestroy(e);
+    if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+    delete c;
+    return QS_OK;
+}
+
+extern "C" const char *qs_last_error(const qs_ctx *c) { return c ? c->err.c_str() : g_create_err.c_str(); }
+
+extern "C" int qs_set_stream(qs_ctx *c, void *hip_stream)
+{
+    ARGCHK(c, c != nullptr);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (hip_stream) {
+        if (c->own_stream) { hipStreamDestroy(c->stream); c->own_stream = false; }
+        c->stream = (hipStream_t)hip_stream;
+    } else if (!c->own_stream) {
+        HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->own_stream = true;
+    }
+    return QS_OK;
+}
+
+extern "C" int qs_sync(qs_ctx *c)
+{
+    ARGCHK(c, c != nullptr);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return QS_OK;
+}
+
+extern "C" int qs_reset(qs_ctx *c)
+{
+    ARGCHK(c, c != nullptr);
+    HIPCHK(c, hipSetDevice(c->device));
+    return reset_state(c);
+}
+
+extern "C" int qs_set_bot_offset(qs_ctx *c, int32_t bot, double off_x)
+{
+    ARGCHK(c, c != nullptr);
+    if (bot < 1 || bot > c->cfg.max_agent) return qs_fail(c, QS_E_RANGE, "qs_set_bot_offset: bot out of range");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(c->d_offset + bot, &off_x, sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return QS_OK;
+}
+
+// ---- timing -------------------------------------------------------------------------------
+static hipEvent_t ev_get(qs_ctx *c)
+{
+    if (!c->ev_pool.empty()) { hipEvent_t e = c->ev_pool.back(); c->ev_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    hipEventCreate(&e);
+    return e;
+}
+struct StageTimer {
+    qs_ctx *c; int stage; hipEvent_t a = nullptr, b = nullptr;
+    StageTimer(qs_ctx *c_, int s) : c(c_), stage(s)
+    { if (c->timing) { a = ev_get(c); b = ev_get(c); hipEventRecord(a, c->stream); } }
+    void stop() { if (c->timing && a) { hipEventRecord(b, c->stream); c->pending.push_back({stage, a, b}); a = nullptr; } }
+};
+
+extern "C" int qs_timing_enable(qs_ctx *c, int32_t enable)
+{
+    ARGCHK(c, c != nullptr);
+    c->timing = enable != 0;
+    return QS_OK;
+}
+
+extern "C" int qs_stage_times(qs_ctx *c, double ms[QS_STAGE_N], uint64_t launches[QS_STAGE_N], int32_t reset)
+{
+    ARGCHK(c, c != nullptr);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (auto &p : c->pending) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, p.a, p.b) == hipSuccess) { c->stage_ms[p.stage] += t; c->stage_launches[p.stage]++; }
+        c->ev_pool.push_back(p.a); c->ev_pool.push_back(p.b);
+    }
+    c->pending.clear();
+    for (int s = 0; s < QS_STAGE_N; s++) { if (ms) ms[s] = c->stage_ms[s]; if (launches) launches[s] = c->stage_launches[s]; }
+    if (reset) for (int s = 0; s < QS_STAGE_N; s++) { c->stage_ms[s] = 0; c->stage_launches[s] = 0; }
+    return QS_OK;
+}
+
+// ---- batch buffers --------------------------------------------------------------------------
+static int ensure_batch(qs_ctx *c, size_t n)
+{
+    if (n <= c->cap_batch) return QS_OK;
+    size_t cap = c->cap_batch ? c->cap_batch : 1024;
+    while (cap < n) cap *= 2;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    QsBatch &b = c->b;
+    HIPCHK(c, dev_realloc(&b.accept, cap)); HIPCHK(c, dev_realloc(&b.agent, cap)); HIPCHK(c, dev_realloc(&b.lm, cap));
+    HIPCHK(c, dev_realloc(&b.px, cap)); HIPCHK(c, dev_realloc(&b.py, cap)); HIPCHK(c, dev_realloc(&b.yaw, cap));
+    HIPCHK(c, dev_realloc(&b.dist, cap)); HIPCHK(c, dev_realloc(&b.enc, cap));
+    HIPCHK(c, dev_realloc(&b.rx, cap)); HIPCHK(c, dev_realloc(&b.ry, cap));
+    HIPCHK(c, dev_realloc(&b.hit, 4 * cap)); HIPCHK(c, dev_realloc(&b.hit_valid, 4 * cap));
+    c->cap_batch = cap;
+    return QS_OK;
+}
+
+// Stamp ordinals are 30 bits (so stamps stay below 2^31 and an int32 MAX all-reduce is valid).
+static int ensure_epoch(qs_ctx *c, uint64_t seq0, size_t n_seq)
+{
+    if (seq0 < c->epoch_base) return qs_fail(c, QS_E_INVAL, "seq0 precedes the current stamp epoch (sequence numbers must not decrease)");
+    const uint64_t limit = (1ull << 28) - 2;
+    if (n_seq > limit) return qs_fail(c, QS_E_RANGE, "batch too large for one stamp epoch (2^28 records)");
+    if (seq0 + n_seq - c->epoch_base > limit) {
+        HIPCHK(c, qs_launch_rebase(c));
+        c->epoch_base = seq0 ? seq0 - 1 : 0;
+        c->n_rebases++;
+    }
+    return QS_OK;
+}
+
+static int reserve_graphs_for_batch(qs_ctx *c, size_t n)
+{
+    bool need_sync = false;
+    for (int g = 0; g < c->n_graphs; g++)
+        if (c->lms_upper[g] + (long long)n > c->h_graphs[g].cap_lms || c->cls_upper[g] + (long long)n > c->h_graphs[g].cap_cls)
+            need_sync = true;
+    if (!need_sync) {
+        for (int g = 0; g < c->n_graphs; g++) { c->lms_upper[g] += (long long)n; c->cls_upper[g] += (long long)n; }
+        return QS_OK;
+    }
+    // tighten the bounds with the exact device-side numbers, then grow what is really short
+    std::vector<QsGraphDev> cur(c->n_graphs);
+    std::vector<unsigned long long> gb((size_t)c->n_graphs * 2);
+    HIPCHK(c, hipMemcpyAsync(cur.data(), c->d_graphs, cur.size() * sizeof(QsGraphDev), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(gb.data(), c->d_graph_batch, gb.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int g = 0; g < c->n_graphs; g++) {
+        const long long ev = (long long)gb[2 * g + 1];
+        const long long need_l = cur[g].n_lms + ev, need_c = cur[g].n_cls + ev;
+        int rc = graph_reserve(c, g, need_l, need_c, cur[g].n_lms, cur[g].n_cls);
+        if (rc != QS_OK) return rc;
+        c->lms_upper[g] = need_l; c->cls_upper[g] = need_c;
+    }
+    return QS_OK;
+}
+
+static int ingest_device(qs_ctx *c, const uint8_t *d_pkts, size_t n, size_t stride, const uint16_t *d_lens,
+                         const double *d_time, uint64_t seq0)
+{
+    if (seq0 == UINT64_MAX) seq0 = c->next_seq;
+    c->last_n = n; c->last_has_poses = true;
+    if (n == 0) return QS_OK;
+    int rc = ensure_batch(c, n);
+    if (rc != QS_OK) return rc;
+    c->b.n = n;
+    rc = ensure_epoch(c, seq0, n);
+    if (rc != QS_OK) return rc;
+    HIPCHK(c, hipMemsetAsync(c->d_graph_batch, 0, (size_t)c->n_graphs * 2 * sizeof(unsigned long long), c->stream));
+    { StageTimer t(c, QS_STAGE_DECODE); HIPCHK(c, qs_launch_decode(c, d_pkts, n, stride, d_lens)); t.stop(); }
+    rc = reserve_graphs_for_batch(c, n);
+    if (rc != QS_OK) return rc;
+    { StageTimer t(c, QS_STAGE_SLAM); HIPCHK(c, qs_launch_slam(c, n)); t.stop(); }
+    {
+        StageTimer t(c, QS_STAGE_RAYCAST);
+        if (c->cfg.raycast_mode == 2) HIPCHK(c, qs_launch_raycast_tiled(c, n, seq0));
+        else HIPCHK(c, qs_launch_raycast_direct(c, n, seq0));
+        t.stop();
+    }
+    if (c->cfg.enable_ekf) { StageTimer t(c, QS_STAGE_EKF); HIPCHK(c, qs_launch_ekf_ingest(c, n, d_time)); t.stop(); }
+    c->next_seq = seq0 + n;
+    return QS_OK;
+}
+
+extern "C" int qs_ingest_device(qs_ctx *c, const uint8_t *d_pkts, size_t n, size_t stride, const uint16_t *d_lens,
+                                const double *d_time, uint64_t seq0)
+{
+    ARGCHK(c, c != nullptr);
+    ARGCHK(c, n == 0 || (d_pkts != nullptr && stride >= QS_PACKET_SIZE_V1));
+    HIPCHK(c, hipSetDevice(c->device));
+    return ingest_device(c, d_pkts, n, stride, d_lens, d_time, seq0);
+}
+
+extern "C" int qs_ingest(qs_ctx *c, const uint8_t *pkts, size_t n, size_t stride, const uint16_t *lens,
+                         const double *recv_time, uint64_t seq0)
+{
+    ARGCHK(c, c != nullptr);
+    ARGCHK(c, n == 0 || (pkts != nullptr && stride >= QS_PACKET_SIZE_V1));
+    HIPCHK(c, hipSetDevice(c->device));
+    if (n == 0) { c->last_n = 0; return QS_OK; }
+    const size_t bytes = n * stride;
+    if (bytes > c->cap_pkts_bytes) {
+        size_t cap = c->cap_pkts_bytes ? c->cap_pkts_bytes : (1u << 16);
+        while (cap < bytes) cap *= 2;
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, dev_realloc(&c->d_pkts, cap));
+        HIPCHK(c, dev_realloc(&c->d_lens, cap / QS_PACKET_SIZE_V1 + 1));
+        HIPCHK(c, dev_realloc(&c->d_time, cap / QS_PACKET_SIZE_V1 + 1));
+        c->cap_pkts_bytes = cap;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_pkts, pkts, bytes, hipMemcpyHostToDevice, c->stream));
+    if (lens) HIPCHK(c, hipMemcpyAsync(c->d_lens, lens, n * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
+    if (recv_time) HIPCHK(c, hipMemcpyAsync(c->d_time, recv_time, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    int rc = ingest_device(c, c->d_pkts, n, stride, lens ? c->d_lens : nullptr, recv_time ? c->d_time : nullptr, seq0);
+    if (rc != QS_OK) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return QS_OK;
+}
+
+extern "C" int qs_last_batch(qs_ctx *c, uint8_t *accepted, double *pose, size_t n)
+{
+    ARGCHK(c, c != nullptr);
+    if (!c->last_has_poses || n != c->last_n) return qs_fail(c, QS_E_INVAL, "qs_last_batch: n does not match the last ingest");
+    if (n == 0) return QS_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<uint8_t> acc(n);
+    HIPCHK(c, hipMemcpyAsync(acc.data(), c->b.accept, n, hipMemcpyDeviceToHost, c->stream));
+    std::vector<double> rx, ry, yaw;
+    if (pose) {
+        rx.resize(n); ry.resize(n); yaw.resize(n);
+        HIPCHK(c, hipMemcpyAsync(rx.data(), c->b.rx, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(ry.data(), c->b.ry, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(yaw.data(), c->b.yaw, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i < n; i++) {
+        if (accepted) accepted[i] = acc[i];
+        if (pose) {
+            pose[3 * i] = acc[i] ? rx[i] : NAN; pose[3 * i + 1] = acc[i] ? ry[i] : NAN; pose[3 * i + 2] = acc[i] ? yaw[i] : NAN;
+        }
+    }
+    return QS_OK;
+}
+
+extern "C" int qs_last_hits(qs_ctx *c, double *xy, uint8_t *valid, size_t n)
+{
+    ARGCHK(c, c != nullptr && xy != nullptr && valid != nullptr);
+    if (!c->last_has_poses || n != c->last_n) return qs_fail(c, QS_E_INVAL, "qs_last_hits: n does not match the last ingest");
+    if (n == 0) return QS_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<uint8_t> acc(n);
+    HIPCHK(c, hipMemcpyAsync(acc.data(), c->b.accept, n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(xy, c->b.hit, 4 * n * sizeof(double2), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(valid, c->b.hit_valid, 4 * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i < n; i++)
+        if (!acc[i]) for (int s = 0; s < 4; s++) valid[4 * i + s] = 0;
+    return QS_OK;
+}
+
+// ---- OccupancyGrid object API ---------------------------------------------------------------
+extern "C" int qs_update_rays(qs_ctx *c, const double *rx, const double *ry, const double *hx, const double *hy,
+                              const uint8_t *valid, size_t n, uint64_t seq0)
+{
+    ARGCHK(c, c != nullptr);
+    if (n == 0) return QS_OK;
+    ARGCHK(c, rx && ry && hx && hy && valid);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (seq0 == UINT64_MAX) seq0 = c->next_seq;
+    const size_t n_seq = (n + 3) / 4;
+    int rc = ensure_epoch(c, seq0, n_seq);
+    if (rc != QS_OK) return rc;
+    double *d = nullptr; unsigned char *dv = nullptr;
+    HIPCHK(c, hipMalloc((void **)&d, 4 * n * sizeof(double)));
+    HIPCHK(c, hipMalloc((void **)&dv, n));
+    hipError_t e = hipSuccess;
+    const double *src[4] = {rx, ry, hx, hy};
+    for (int q = 0; q < 4 && e == hipSuccess; q++)
+        e = hipMemcpyAsync(d + q * n, src[q], n * sizeof(double), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dv, valid, n, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = qs_launch_update_rays(c, d, d + n, d + 2 * n, d + 3 * n, dv, n, seq0);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(d); hipFree(dv);
+    if (e != hipSuccess) return qs_fail(c, QS_E_HIP, "qs_update_rays", e);
+    c->next_seq = seq0 + n_seq;
+    c->last_has_poses = false;
+    return QS_OK;
+}
+
+extern "C" int qs_world_to_grid(qs_ctx *c, const double *w, size_t n, int32_t axis, int64_t *out)
+{
+    ARGCHK(c, c != nullptr);
+    if (n == 0) return QS_OK;
+    ARGCHK(c, w && out);
+    HIPCHK(c, hipSetDevice(c->device));
+    double *d = nullptr; long long *o = nullptr;
+    HIPCHK(c, hipMalloc((void **)&d, n * sizeof(double)));
+    HIPCHK(c, hipMalloc((void **)&o, n * sizeof(long long)));
+    hipError_t e = hipMemcpyAsync(d, w, n * sizeof(double), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = qs_launch_world_to_grid(c, d, n, axis, o);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, o, n * sizeof(long long), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(d); hipFree(o);
+    if (e != hipSuccess) return qs_fail(c, QS_E_HIP, "qs_world_to_grid", e);
+    return QS_OK;
+}
+
+extern "C" int qs_grid_i8_device(qs_ctx *c, int8_t *out_dev)
+{
+    ARGCHK(c, c != nullptr && out_dev != nullptr);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, qs_launch_view_i8(c, (signed char *)out_dev));
+    return QS_OK;
+}
+
+extern "C" int qs_grid_i8(qs_ctx *c, int8_t *out_host)
+{
+    ARGCHK(c, c != nullptr && out_host != nullptr);
+    HIPCHK(c, hipSetDevice(c->device));
+    signed char *d = nullptr;
+    HIPCHK(c, hipMalloc((void **)&d, c->cells));
+    hipError_t e = qs_launch_view_i8(c, d);
+    if (e == hipSuccess) e = hipMemcpyAsync(out_host, d, c->cells, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(d);
+    if (e != hipSuccess) return qs_fail(c, QS_E_HIP, "qs_grid_i8", e);
+    return QS_OK;
+}
+
+extern "C" int qs_grid_counts(qs_ctx *c, int32_t *hits_host, int32_t *misses_host)
+{
+    ARGCHK(c, c != nullptr && hits_host && misses_host);
+    if (!c->d_counts) return qs_fail(c, QS_E_INVAL, "qs_grid_counts: context created with enable_counts = 0");
+    HIPCHK(c, hipSetDevice(c->device));
+    int *d = nullptr;
+    HIPCHK(c, hipMalloc((void **)&d, 2 * c->cells * sizeof(int)));
+    hipError_t e = qs_launch_split_counts(c, d, d + c->cells);
+    if (e == hipSuccess) e = hipMemcpyAsync(hits_host, d, c->cells * sizeof(int), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(misses_host, d + c->cells, c->cells * sizeof(int), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(d);
+    if (e != hipSuccess) return qs_fail(c, QS_E_HIP, "qs_grid_counts", e);
+    return QS_OK;
+}
+
+extern "C" int qs_grid_logodds(qs_ctx *c, float l_occ, float l_free, float lmin, float lmax, float *out_host)
+{
+    ARGCHK(c, c != nullptr && out_host);
+    if (!c->d_counts) return qs_fail(c, QS_E_INVAL, "qs_grid_logodds: context created with enable_counts = 0");
+    HIPCHK(c, hipSetDevice(c->device));
+    float *d = nullptr;
+    HIPCHK(c, hipMalloc((void **)&d, c->cells * sizeof(float)));
+    hipError_t e = qs_launch_logodds(c, l_occ, l_free, lmin, lmax, d);
+    if (e == hipSuccess) e = hipMemcpyAsync(out_host, d, c->cells * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(d);
+    if (e != hipSuccess) return qs_fail(c, QS_E_HIP, "qs_grid_logodds", e);
+    return QS_OK;
+}
+
+extern "C" int qs_device_buffers(qs_ctx *c, void **stamps_dev, size_t *stamps_bytes, void **counts_dev, size_t *counts_bytes)
+{
+    ARGCHK(c, c != nullptr);
+    if (stamps_dev) *stamps_dev = c->d_stamps;
+    if (stamps_bytes) *stamps_bytes = c->cells * sizeof(unsigned int);
+    if (counts_dev) *counts_dev = c->d_counts;
+    if (counts_bytes) *counts_bytes = c->d_counts ? c->cells * sizeof(unsigned long long) : 0;
+    return QS_OK;
+}
+
+// ---- SLAM state -------------------------------------------------------------------------------
+static int read_graph(qs_ctx *c, int32_t graph, QsGraphDev &g)
+{
+    if (graph < 0 || graph >= c->n_graphs) return qs_fail(c, QS_E_RANGE, "graph index out of range");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(&g, c->d_graphs + graph, sizeof g, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return QS_OK;
+}
+
+extern "C" int qs_slam_sizes(qs_ctx *c, int32_t graph, int64_t *n_nodes, int64_t *n_landmarks, int64_t *n_closures)
+{
+    ARGCHK(c, c != nullptr);
+    QsGraphDev g;
+    int rc = read_graph(c, graph, g);
+    if (rc != QS_OK) return rc;
+    if (n_nodes) *n_nodes = g.n_nodes;
+    if (n_landmarks) *n_landmarks = g.n_lms;
+    if (n_closures) *n_closures = g.n_cls;
+    return QS_OK;
+}
+
+extern "C" int qs_slam_closures(qs_ctx *c, int32_t graph, int64_t *idx2, double *corr2, size_t cap)
+{
+    ARGCHK(c, c != nullptr && idx2 && corr2);
+    QsGraphDev g;
+    int rc = read_graph(c, graph, g);
+    if (rc != QS_OK) return rc;
+    const size_t n = (size_t)g.n_cls;
+    if (n > cap) return qs_fail(c, QS_E_RANGE, "qs_slam_closures: capacity too small");
+    if (n == 0) return QS_OK;
+    std::vector<long long> a(n), b(n); std::vector<double> dx(n), dy(n);
+    HIPCHK(c, hipMemcpy(a.data(), g.cl_lm_idx, n * 8, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(b.data(), g.cl_node_idx, n * 8, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(dx.data(), g.cl_dx, n * 8, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(dy.data(), g.cl_dy, n * 8, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; i++) { idx2[2 * i] = a[i]; idx2[2 * i + 1] = b[i]; corr2[2 * i] = dx[i]; corr2[2 * i + 1] = dy[i]; }
+    return QS_OK;
+}
+
+extern "C" int qs_slam_landmarks(qs_ctx *c, int32_t graph, double *xy, int64_t *type_idx, size_t cap)
+{
+    ARGCHK(c, c != nullptr && xy && type_idx);
+    QsGraphDev g;
+    int rc = read_graph(c, graph, g);
+    if (rc != QS_OK) return rc;
+    const size_t n = (size_t)g.n_lms;
+    if (n > cap) return qs_fail(c, QS_E_RANGE, "qs_slam_landmarks: capacity too small");
+    if (n == 0) return QS_OK;
+    std::vector<double> x(n), y(n); std::vector<long long> idx(n); std::vector<unsigned char> t(n);
+    HIPCHK(c, hipMemcpy(x.data(), g.lm_x, n * 8, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(y.data(), g.lm_y, n * 8, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(idx.data(), g.lm_idx, n * 8, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(t.data(), g.lm_type, n, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; i++) { xy[2 * i] = x[i]; xy[2 * i + 1] = y[i]; type_idx[2 * i] = t[i]; type_idx[2 * i + 1] = idx[i]; }
+    return QS_OK;
+}
+
+extern "C" int qs_drift(qs_ctx *c, int32_t bot, double out[2])
+{
+    ARGCHK(c, c != nullptr && out);
+    if (bot < 1 || bot > c->cfg.max_agent) return qs_fail(c, QS_E_RANGE, "qs_drift: bot out of range");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(out, c->d_drift + 2 * bot, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return QS_OK;
+}
+
+// ---- ZONE ---------------------------------------------------------------------------------------
+extern "C" int qs_zone(qs_ctx *c, int32_t bot, double out[4], int32_t *valid)
+{
+    ARGCHK(c, c != nullptr && out && valid);
+    if (bot < 1 || bot > c->cfg.max_agent) return qs_fail(c, QS_E_RANGE, "qs_zone: bot out of range");
+    HIPCHK(c, hipSetDevice(c->device));
+    unsigned long long z[4];
+    HIPCHK(c, hipMemcpyAsync(z, c->d_zone + 4 * bot, sizeof z, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *valid = z[0] != QS_ORD_MIN_IDENT;                      // compute_bounding_box: None if no points  :704
+    for (int i = 0; i < 4; i++) out[i] = *valid ? qs_double_from_ord(z[i]) : NAN;
+    return QS_OK;
+}
+
+extern "C" int qs_zone_packet(qs_ctx *c, int32_t bot, int32_t online, uint8_t out[QS_ZONE_SIZE])
+{
+    ARGCHK(c, c != nullptr && out);
+    float f[4] = {999.0f, 999.0f, -999.0f, -999.0f};       // send_zone_to_bot(None)  :679-681
+    if (online) {
+        double z[4]; int32_t valid = 0;
+        int rc = qs_zone(c, bot, z, &valid);
+        if (rc != QS_OK) return rc;
+        if (valid) for (int i = 0; i < 4; i++) f[i] = (float)z[i];   // struct.pack('<4sffff')  :683-684
+    }
+    memcpy(out, "ZONE", 4);
+    memcpy(out + 4, f, 16);
+    return QS_OK;
+}
+
+// ---- fuse / merge ---------------------------------------------------------------------------------
+extern "C" int qs_fuse_buffers(qs_ctx *c, const void *const *stamps_dev, const void *const *counts_dev, size_t n)
+{
+    ARGCHK(c, c != nullptr);
+    if (n == 0) return QS_OK;
+    ARGCHK(c, stamps_dev != nullptr);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, qs_launch_fuse(c, (const unsigned int *const *)stamps_dev, (const unsigned long long *const *)counts_dev, n));
+    return QS_OK;
+}
+
+extern "C" int qs_fuse(qs_ctx *dst, qs_ctx *const *srcs, size_t n)
+{
+    ARGCHK(dst, dst != nullptr);
+    if (n == 0) return QS_OK;
+    ARGCHK(dst, srcs != nullptr);
+    std::vector<const void *> st(n), ct(n);
+    bool counts = dst->d_counts != nullptr;
+    for (size_t i = 0; i < n; i++) {
+        qs_ctx *s = srcs[i];
+        if (!s || s->device != dst->device || s->cfg.size != dst->cfg.size || s->cfg.res != dst->cfg.res ||
+            s->cfg.ox != dst->cfg.ox || s->cfg.oy != dst->cfg.oy)
+            return qs_fail(dst, QS_E_INVAL, "qs_fuse: source grids must share device and geometry with dst");
+        if (s->epoch_base != dst->epoch_base)
+            return qs_fail(dst, QS_E_INVAL, "qs_fuse: source and destination are in different stamp epochs");
+        HIPCHK(dst, hipStreamSynchronize(s->stream));
+        st[i] = s->d_stamps; ct[i] = s->d_counts;
+        if (!s->d_counts) counts = false;
+    }
+    int rc = qs_fuse_buffers(dst, st.data(), counts ? ct.data() : nullptr, n);
+    if (rc != QS_OK) return rc;
+    HIPCHK(dst, hipStreamSynchronize(dst->stream));
+    return QS_OK;
+}
+
+extern "C" int qs_grid_to_pcd(qs_ctx *c, const int8_t *grid, int32_t h, int32_t w, double res, double ox, double oy,
+                              double *xy, size_t cap, size_t *n_out)
+{
+    ARGCHK(c, c != nullptr && grid != nullptr && n_out != nullptr && h > 0 && w > 0);
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t cells = (size_t)h * w, n_chunks = (cells + 1023) / 1024;
+    signed char *dg = nullptr; unsigned int *dchunk = nullptr; unsigned long long *dcount = nullptr; double *dxy = nullptr;
+    hipError_t e = hipMalloc((void **)&dg, cells);
+    if (e == hipSuccess) e = hipMalloc((void **)&dchunk, n_chunks * sizeof(unsigned int));
+    if (e == hipSuccess) e = hipMalloc((void **)&dcount, sizeof(unsigned long long));
+    unsigned long long total = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(dg, grid, cells, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = qs_launch_grid_to_pcd(c, dg, h, w, res, ox, oy, nullptr, 0, dcount, dchunk);
+    if (e == hipSuccess) e = hipMemcpyAsync(&total, dcount, sizeof total, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    *n_out = (size_t)total;
+    if (e == hipSuccess && xy && total > 0) {
+        const size_t m = total < cap ? (size_t)total : cap;
+        e = hipMalloc((void **)&dxy, 2 * (size_t)total * sizeof(double));
+        if (e == hipSuccess) e = qs_launch_grid_to_pcd(c, dg, h, w, res, ox, oy, dxy, (size_t)total, dcount, dchunk);
+        if (e == hipSuccess) e = hipMemcpyAsync(xy, dxy, 2 * m * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    }
+    hipFree(dg); hipFree(dchunk); hipFree(dcount); hipFree(dxy);
+    if (e != hipSuccess) return qs_fail(c, QS_E_HIP, "qs_grid_to_pcd", e);
+    return QS_OK;
+}
+
+extern "C" int qs_rasterise(qs_ctx *c, const double *xy, size_t n, double res, int32_t dims[2], double origin[2], int8_t *grid)
+{
+    ARGCHK(c, c != nullptr && dims && origin && res > 0);
+    if (n == 0) { dims[0] = dims[1] = 0; return QS_OK; }      // publish_global_map returns early  :88-93
+    ARGCHK(c, xy != nullptr);
+    HIPCHK(c, hipSetDevice(c->device));
+    double *dxy = nullptr; unsigned long long *dbox = nullptr; signed char *dg = nullptr;
+    unsigned long long box[4] = {QS_ORD_MIN_IDENT, QS_ORD_MIN_IDENT, QS_ORD_MAX_IDENT, QS_ORD_MAX_IDENT};
+    hipError_t e = hipMalloc((void **)&dxy, 2 * n * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void **)&dbox, sizeof box);
+    if (e == hipSuccess) e = hipMemcpyAsync(dxy, xy, 2 * n * sizeof(double), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dbox, box, sizeof box, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = qs_launch_bbox(c, dxy, n, dbox);
+    if (e == hipSuccess) e = hipMemcpyAsync(box, dbox, sizeof box, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    int rc = QS_OK;
+    if (e == hipSuccess) {
+        const double mnx = qs_double_from_ord(box[0]), mny = qs_double_from_ord(box[1]);
+        const double mxx = qs_double_from_ord(box[2]), mxy = qs_double_from_ord(box[3]);
+        const double wd = ceil((mxx - mnx) / res), hd = ceil((mxy - mny) / res);     // :103-104
+        if (!(wd >= 0 && wd < 65536 && hd >= 0 && hd < 65536)) rc = qs_fail(c, QS_E_RANGE, "qs_rasterise: canvas too large");
+        else {
+            const int w = (int)wd + 1, h = (int)hd + 1;
+            dims[0] = h; dims[1] = w; origin[0] = mnx; origin[1] = mny;
+            if (grid) {
+                e = hipMalloc((void **)&dg, (size_t)h * w);
+                if (e == hipSuccess) e = qs_launch_rasterise(c, dxy, n, res, mnx, mny, h, w, dg);
+                if (e == hipSuccess) e = hipMemcpyAsync(grid, dg, (size_t)h * w, hipMemcpyDeviceToHost, c->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            }
+        }
+    }
+    hipFree(dxy); hipFree(dbox); hipFree(dg);
+    if (e != hipSuccess) return qs_fail(c, QS_E_HIP, "qs_rasterise", e);
+    return rc;
+}
+
+// ---- EKF --------------------------------------------------------------------------------------------
+extern "C" int qs_ekf_init(qs_ctx *c, int32_t bot, double t, const double x0[6])
+{
+    ARGCHK(c, c != nullptr);
+    if (bot < 1 || bot > c->cfg.max_agent) return qs_fail(c, QS_E_RANGE, "qs_ekf_init: bot out of range");
+    HIPCHK(c, hipSetDevice(c->device));
+    double f[44] = {0};
+    for (int i = 0; i < 6; i++) { f[i] = x0 ? x0[i] : 0.0; f[6 + 7 * i] = 1.0; }     // x0, P = I  ekf.cpp:5-19
+    f[42] = t; f[43] = 1.0;
+    HIPCHK(c, hipMemcpyAsync(c->d_ekf + (size_t)bot * 44, f, sizeof f, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return QS_OK;
+}
+
+extern "C" int qs_ekf_step(qs_ctx *c, const int32_t *bot_ids, const double *omega_m, const double *t, const double *z_v,
+                           const double *z_omega, size_t n, int32_t do_update)
+{
+    ARGCHK(c, c != nullptr);
+    if (n == 0) return QS_OK;
+    ARGCHK(c, bot_ids && omega_m && t && (!do_update || (z_v && z_omega)));
+    HIPCHK(c, hipSetDevice(c->device));
+    int *db = nullptr; double *dd = nullptr;
+    hipError_t e = hipMalloc((void **)&db, n * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void **)&dd, 4 * n * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpyAsync(db, bot_ids, n * sizeof(int), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dd, omega_m, n * 8, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dd + n, t, n * 8, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && do_update) e = hipMemcpyAsync(dd + 2 * n, z_v, n * 8, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && do_update) e = hipMemcpyAsync(dd + 3 * n, z_omega, n * 8, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = qs_launch_ekf_step(c, db, dd, dd + n, dd + 2 * n, dd + 3 * n, n, do_update);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(db); hipFree(dd);
+    if (e != hipSuccess) return qs_fail(c, QS_E_HIP, "qs_ekf_step", e);
+    return QS_OK;
+}
+
+extern "C" int qs_ekf_state(qs_ctx *c, int32_t bot, double x[6], double P[36])
+{
+    ARGCHK(c, c != nullptr);
+    if (bot < 1 || bot > c->cfg.max_agent) return qs_fail(c, QS_E_RANGE, "qs_ekf_state: bot out of range");
+    HIPCHK(c, hipSetDevice(c->device));
+    double f[44];
+    HIPCHK(c, hipMemcpyAsync(f, c->d_ekf + (size_t)bot * 44, sizeof f, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (x) memcpy(x, f, 6 * sizeof(double));
+    if (P) memcpy(P, f + 6, 36 * sizeof(double));
+    return QS_OK;
+}
+
+extern "C" int qs_counters(qs_ctx *c, uint64_t out[QS_CNT_N])
+{
+    ARGCHK(c, c != nullptr && out);
+    HIPCHK(c, hipSetDevice(c->device));
+    unsigned long long v[QS_CNT_N];
+    HIPCHK(c, hipMemcpyAsync(v, c->d_counters, sizeof v, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < QS_CNT_N; i++) out[i] = v[i];
+    out[QS_CNT_REBASES] = c->n_rebases;
+    return QS_OK;
+}

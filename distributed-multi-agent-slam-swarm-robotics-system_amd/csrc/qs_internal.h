@@ -1,0 +1,150 @@
+// qs_internal.h -- shared declarations of the HIP implementation behind include/quasar_slam.h
+// gfx950 only.  All device arithmetic that decides a cell index or a loop closure is fp64
+// with -ffp-contract=off (the reference is CPython double arithmetic).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/quasar_slam.h"
+
+#define QS_WAVE 64
+#define QS_MAX_AGENT 255          // agent_id is one byte on the wire (dual_bot_mapper.py:41)
+#define QS_WIN_MAX 32             // SLAM window: min(min_poses_between, 32) consecutive nodes
+
+// ---- monotone double <-> uint64 map for atomic min/max of zone boxes --------------------
+__host__ __device__ inline unsigned long long qs_ord_from_double(double d)
+{
+    unsigned long long b;
+    __builtin_memcpy(&b, &d, 8);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__host__ __device__ inline double qs_double_from_ord(unsigned long long k)
+{
+    unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    double d;
+    __builtin_memcpy(&d, &b, 8);
+    return d;
+}
+#define QS_ORD_MIN_IDENT 0xffffffffffffffffull   // identity for atomicMin
+#define QS_ORD_MAX_IDENT 0ull                    // identity for atomicMax
+
+// ---- per pose-graph device state (PoseGraphSLAM, dual_bot_mapper.py:261-271) -------------
+struct QsGraphDev {
+    long long n_nodes;     // len(self.nodes)
+    long long n_lms;       // len(self.landmarks)
+    long long n_cls;       // len(self.closures)
+    long long cap_lms, cap_cls;
+    double *lm_x, *lm_y;   // landmark position (pose of the storing packet, pre-closure)
+    long long *lm_idx;     // node index of the storing packet (ascending)
+    unsigned char *lm_type;
+    long long *cl_lm_idx, *cl_node_idx;
+    double *cl_dx, *cl_dy;
+};
+
+// ---- geometry / constants passed by value to kernels ------------------------------------
+struct QsGeom {
+    int size;
+    double res, ox, oy;
+    double min_dist, max_dist;
+};
+
+// ---- decoded batch (SoA, one slot per datagram of the batch) -----------------------------
+struct QsBatch {
+    size_t n;
+    unsigned char *accept;   // 1 = passes dual_bot_mapper.py:826-843
+    unsigned char *agent;    // agent_id
+    unsigned char *lm;       // landmark_type (0 for v1 packets)
+    double *px, *py, *yaw;   // f32 fields widened; px already has the bot offset (:851-852)
+    float4 *dist;            // front, left, back, right (metres)
+    int *enc;                // encoder ticks
+    double *rx, *ry;         // pose after drift correction (:855-857), written by the SLAM stage
+    double2 *hit;            // 4 per datagram: ray end points (valid hits only meaningful)
+    unsigned char *hit_valid;
+};
+
+struct qs_ctx {
+    qs_config cfg;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    size_t cells = 0;
+    int n_graphs = 0, bots_per_graph = 0, win = 30;
+    double r2_threshold = 0.0;   // s < r2_threshold  <=>  sqrt(s) < closure_radius
+    QsGeom geom;
+
+    unsigned int *d_stamps = nullptr;            // [size][size]; 0 = UNKNOWN, else (ordinal<<1)|occ
+    unsigned long long *d_counts = nullptr;      // [size][size]; hi32 = hits, lo32 = misses
+    double *d_offset = nullptr;                  // [max_agent+1]
+    double *d_drift = nullptr;                   // [max_agent+1][2]
+    long long *d_last_closure = nullptr;         // [max_agent+1]
+    unsigned long long *d_zone = nullptr;        // [max_agent+1][4] ordered-u64 minx,miny,maxx,maxy
+    unsigned long long *d_counters = nullptr;    // [QS_CNT_N]
+    unsigned long long *d_graph_batch = nullptr; // [n_graphs][2]: accepted, landmark events of the batch
+    double *d_ekf = nullptr;                     // [max_agent+1][44]
+    double *d_ekf_prev = nullptr;                // [max_agent+1][4]
+
+    QsGraphDev *d_graphs = nullptr;
+    std::vector<QsGraphDev> h_graphs;            // host mirror of pointers/capacities
+    std::vector<long long> lms_upper, cls_upper; // host upper bounds on n_lms / n_cls
+
+    // batch staging
+    size_t cap_batch = 0;
+    unsigned char *d_pkts = nullptr; size_t cap_pkts_bytes = 0;
+    unsigned short *d_lens = nullptr;
+    double *d_time = nullptr;
+    QsBatch b{};
+    size_t last_n = 0;
+    bool last_has_poses = false;
+
+    // tile-binned raycast workspace
+    void *d_bin_ws = nullptr; size_t bin_ws_bytes = 0;
+
+    uint64_t next_seq = 0, epoch_base = 0, n_rebases = 0;
+
+    // timing
+    bool timing = false;
+    hipEvent_t ev[QS_STAGE_N][2]{};
+    bool ev_created = false;
+    struct Pending { int stage; hipEvent_t a, b; };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> ev_pool;
+    double stage_ms[QS_STAGE_N]{};
+    uint64_t stage_launches[QS_STAGE_N]{};
+};
+
+// ---- kernel launchers (each defined next to its kernel) ----------------------------------
+// decode.hip
+hipError_t qs_launch_decode(qs_ctx *c, const unsigned char *d_pkts, size_t n, size_t stride,
+                            const unsigned short *d_lens);
+// slam.hip
+hipError_t qs_launch_slam(qs_ctx *c, size_t n);
+// raycast.hip
+hipError_t qs_launch_raycast_direct(qs_ctx *c, size_t n, uint64_t seq0);
+hipError_t qs_launch_update_rays(qs_ctx *c, const double *rx, const double *ry, const double *hx,
+                                 const double *hy, const unsigned char *valid, size_t n,
+                                 uint64_t seq0);
+hipError_t qs_launch_world_to_grid(qs_ctx *c, const double *w, size_t n, int axis, long long *out);
+// raycast_tiled.hip
+hipError_t qs_launch_raycast_tiled(qs_ctx *c, size_t n, uint64_t seq0);
+size_t qs_tiled_workspace_bytes(const qs_ctx *c, size_t n);
+// grid_ops.hip
+hipError_t qs_launch_view_i8(qs_ctx *c, signed char *out_dev);
+hipError_t qs_launch_logodds(qs_ctx *c, float l_occ, float l_free, float lmin, float lmax, float *out_dev);
+hipError_t qs_launch_split_counts(qs_ctx *c, int *hits_dev, int *misses_dev);
+hipError_t qs_launch_rebase(qs_ctx *c);
+hipError_t qs_launch_fuse(qs_ctx *c, const unsigned int *const *d_src_stamps,
+                          const unsigned long long *const *d_src_counts, size_t n_src);
+hipError_t qs_launch_fill_zone_identity(qs_ctx *c);
+hipError_t qs_launch_grid_to_pcd(qs_ctx *c, const signed char *d_grid, int h, int w, double res,
+                                 double ox, double oy, double *d_xy, size_t cap,
+                                 unsigned long long *d_count, unsigned int *d_rowcount);
+hipError_t qs_launch_rasterise(qs_ctx *c, const double *d_xy, size_t n, double res, double minx,
+                               double miny, int h, int w, signed char *d_grid);
+hipError_t qs_launch_bbox(qs_ctx *c, const double *d_xy, size_t n, unsigned long long *d_box4);
+// ekf.hip
+hipError_t qs_launch_ekf_ingest(qs_ctx *c, size_t n, const double *d_time);
+hipError_t qs_launch_ekf_step(qs_ctx *c, const int *d_bots, const double *d_omega, const double *d_t,
+                              const double *d_zv, const double *d_zo, size_t n, int do_update);

@@ -1,0 +1,175 @@
+// raycast.hip -- K1 (direct form): 4-ray inverse sensor model into the global grid with one
+// global atomic per cell.  Semantics: server_nodes/dual_bot_mapper.py:882-903 (projection and
+// trust filter), :136-179 (update_ray + the strict-inequality Bresenham variant), :121-125
+// (world_to_grid: fp64 subtract, fp64 divide, truncate).
+//
+// Order dependence: the reference overwrites cells, so the last write in arrival order wins.
+// Every cell write carries a stamp (ordinal << 1) | occ with ordinal = 4*seq + sensor + 1;
+// atomicMax makes any schedule produce the sequential answer.  Cells of one ray are distinct,
+// so ties never occur.  Hit/miss counters are a 64-bit atomicAdd (hi32 hits, lo32 misses).
+//
+// This direct kernel is the reference point for correctness and the fallback for streams
+// with no spatial locality; raycast_tiled.hip is the LDS-staged production path.
+#include "qs_internal.h"
+#include "raycast_common.h"
+
+#define RC_BLOCK 256
+
+template <bool COUNTS>
+__global__ void __launch_bounds__(RC_BLOCK)
+qs_raycast_direct_kernel(size_t n, QsBatch b, QsGeom geo, unsigned int *__restrict__ stamps,
+                         unsigned long long *__restrict__ counts, unsigned long long ord_base,
+                         unsigned long long *__restrict__ zone, int max_agent,
+                         unsigned long long *__restrict__ counters)
+{
+    __shared__ unsigned long long s_zone[QS_MAX_AGENT + 1][4];
+    __shared__ unsigned int s_cnt[3];
+    const int tid = threadIdx.x;
+    for (int t = tid; t <= max_agent; t += RC_BLOCK) {
+        s_zone[t][0] = QS_ORD_MIN_IDENT; s_zone[t][1] = QS_ORD_MIN_IDENT;
+        s_zone[t][2] = QS_ORD_MAX_IDENT; s_zone[t][3] = QS_ORD_MAX_IDENT;
+    }
+    if (tid < 3) s_cnt[tid] = 0;
+    __syncthreads();
+
+    const size_t r = (size_t)blockIdx.x * RC_BLOCK + tid;   // ray id: 4 per datagram
+    const size_t i = r >> 2;
+    const int s = (int)(r & 3);
+    unsigned int my_cells = 0, my_ray = 0, my_hit = 0;
+    if (i < n && b.accept[i]) {
+        const double rx = b.rx[i], ry = b.ry[i], yaw = b.yaw[i];
+        const float4 d4 = b.dist[i];
+        const float df = s == 0 ? d4.x : (s == 1 ? d4.y : (s == 2 ? d4.z : d4.w));
+        const int agent = b.agent[i];
+        QsRay ray = qs_project_ray(rx, ry, yaw, (double)df, s, geo);
+        b.hit[r] = make_double2(ray.ex, ray.ey);
+        b.hit_valid[r] = ray.valid ? 1 : 0;
+        if (s == 0) {   // paths[agent].append  :878-879
+            atomicMin(&s_zone[agent][0], qs_ord_from_double(rx)); atomicMin(&s_zone[agent][1], qs_ord_from_double(ry));
+            atomicMax(&s_zone[agent][2], qs_ord_from_double(rx)); atomicMax(&s_zone[agent][3], qs_ord_from_double(ry));
+        }
+        if (ray.valid) {  // point_clouds[agent][name].append  :892
+            atomicMin(&s_zone[agent][0], qs_ord_from_double(ray.ex)); atomicMin(&s_zone[agent][1], qs_ord_from_double(ray.ey));
+            atomicMax(&s_zone[agent][2], qs_ord_from_double(ray.ex)); atomicMax(&s_zone[agent][3], qs_ord_from_double(ray.ey));
+            my_hit = 1;
+        }
+        my_ray = 1;
+        const unsigned int key_free = (unsigned int)((ord_base + 4ull * i + s + 1) << 1);
+        QsLine ln;
+        if (qs_line_setup(ray, rx, ry, geo, ln)) {
+            int x = ln.x0, y = ln.y0, err = ln.dx - ln.dy;
+            for (;;) {
+                const bool last = (x == ln.x1 && y == ln.y1);
+                if ((!last || ray.valid) && x >= 0 && x < geo.size && y >= 0 && y < geo.size) {
+                    const size_t c = (size_t)y * geo.size + x;
+                    atomicMax(&stamps[c], key_free | (last ? 1u : 0u));
+                    if (COUNTS) atomicAdd(&counts[c], last ? (1ull << 32) : 1ull);
+                    my_cells++;
+                }
+                if (last) break;
+                const int e2 = 2 * err;
+                if (e2 > -ln.dy) { err -= ln.dy; x += ln.sx; }
+                if (e2 < ln.dx) { err += ln.dx; y += ln.sy; }
+            }
+        }
+    }
+    // block-level counters and zone flush
+    if (my_ray) atomicAdd(&s_cnt[0], my_ray);
+    if (my_cells) atomicAdd(&s_cnt[1], my_cells);
+    if (my_hit) atomicAdd(&s_cnt[2], my_hit);
+    __syncthreads();
+    for (int t = tid; t <= max_agent; t += RC_BLOCK) {
+        if (s_zone[t][0] != QS_ORD_MIN_IDENT) {
+            atomicMin(&zone[4 * t + 0], s_zone[t][0]); atomicMin(&zone[4 * t + 1], s_zone[t][1]);
+            atomicMax(&zone[4 * t + 2], s_zone[t][2]); atomicMax(&zone[4 * t + 3], s_zone[t][3]);
+        }
+    }
+    if (tid == 0) {
+        if (s_cnt[0]) atomicAdd(&counters[QS_CNT_RAYS], (unsigned long long)s_cnt[0]);
+        if (s_cnt[1]) atomicAdd(&counters[QS_CNT_CELLS], (unsigned long long)s_cnt[1]);
+        if (s_cnt[2]) atomicAdd(&counters[QS_CNT_HITS], (unsigned long long)s_cnt[2]);
+    }
+}
+
+hipError_t qs_launch_raycast_direct(qs_ctx *c, size_t n, uint64_t seq0)
+{
+    if (n == 0) return hipSuccess;
+    const unsigned int blocks = (unsigned int)((4 * n + RC_BLOCK - 1) / RC_BLOCK);
+    const unsigned long long ord_base = 4ull * (seq0 - c->epoch_base);
+    if (c->cfg.enable_counts)
+        hipLaunchKernelGGL(qs_raycast_direct_kernel<true>, dim3(blocks), dim3(RC_BLOCK), 0, c->stream, n,
+                           c->b, c->geom, c->d_stamps, c->d_counts, ord_base, c->d_zone,
+                           c->cfg.max_agent, c->d_counters);
+    else
+        hipLaunchKernelGGL(qs_raycast_direct_kernel<false>, dim3(blocks), dim3(RC_BLOCK), 0, c->stream, n,
+                           c->b, c->geom, c->d_stamps, c->d_counts, ord_base, c->d_zone,
+                           c->cfg.max_agent, c->d_counters);
+    return hipGetLastError();
+}
+
+// ---- OccupancyGrid.update_ray, batched (object API, :136-156) ----------------------------
+// Ray k is written after ray k-1: ordinal = seq0*4 + k + 1 in the same stamp space.
+template <bool COUNTS>
+__global__ void __launch_bounds__(RC_BLOCK)
+qs_update_rays_kernel(size_t n, const double *__restrict__ rx, const double *__restrict__ ry,
+                      const double *__restrict__ hx, const double *__restrict__ hy,
+                      const unsigned char *__restrict__ valid, QsGeom geo,
+                      unsigned int *__restrict__ stamps, unsigned long long *__restrict__ counts,
+                      unsigned long long ord_base, unsigned long long *__restrict__ counters)
+{
+    const size_t k = (size_t)blockIdx.x * RC_BLOCK + threadIdx.x;
+    if (k >= n) return;
+    QsRay ray; ray.ex = hx[k]; ray.ey = hy[k]; ray.valid = valid[k] != 0;
+    const unsigned int key_free = (unsigned int)((ord_base + k + 1) << 1);
+    QsLine ln;
+    unsigned int cells = 0;
+    if (isfinite(rx[k]) && isfinite(ry[k]) && isfinite(ray.ex) && isfinite(ray.ey) &&
+        qs_line_setup(ray, rx[k], ry[k], geo, ln)) {
+        int x = ln.x0, y = ln.y0, err = ln.dx - ln.dy;
+        for (;;) {
+            const bool last = (x == ln.x1 && y == ln.y1);
+            if ((!last || ray.valid) && x >= 0 && x < geo.size && y >= 0 && y < geo.size) {
+                const size_t c = (size_t)y * geo.size + x;
+                atomicMax(&stamps[c], key_free | (last ? 1u : 0u));
+                if (COUNTS) atomicAdd(&counts[c], last ? (1ull << 32) : 1ull);
+                cells++;
+            }
+            if (last) break;
+            const int e2 = 2 * err;
+            if (e2 > -ln.dy) { err -= ln.dy; x += ln.sx; }
+            if (e2 < ln.dx) { err += ln.dx; y += ln.sy; }
+        }
+    }
+    atomicAdd(&counters[QS_CNT_RAYS], 1ull);
+    if (cells) atomicAdd(&counters[QS_CNT_CELLS], (unsigned long long)cells);
+}
+
+hipError_t qs_launch_update_rays(qs_ctx *c, const double *rx, const double *ry, const double *hx,
+                                 const double *hy, const unsigned char *valid, size_t n, uint64_t seq0)
+{
+    if (n == 0) return hipSuccess;
+    const unsigned int blocks = (unsigned int)((n + RC_BLOCK - 1) / RC_BLOCK);
+    const unsigned long long ord_base = 4ull * (seq0 - c->epoch_base);
+    if (c->cfg.enable_counts)
+        hipLaunchKernelGGL(qs_update_rays_kernel<true>, dim3(blocks), dim3(RC_BLOCK), 0, c->stream, n, rx, ry,
+                           hx, hy, valid, c->geom, c->d_stamps, c->d_counts, ord_base, c->d_counters);
+    else
+        hipLaunchKernelGGL(qs_update_rays_kernel<false>, dim3(blocks), dim3(RC_BLOCK), 0, c->stream, n, rx, ry,
+                           hx, hy, valid, c->geom, c->d_stamps, c->d_counts, ord_base, c->d_counters);
+    return hipGetLastError();
+}
+
+__global__ void qs_world_to_grid_kernel(const double *__restrict__ w, size_t n, double o, double res,
+                                        long long *__restrict__ out)
+{
+    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) out[k] = qs_w2g_ll(w[k], o, res);
+}
+
+hipError_t qs_launch_world_to_grid(qs_ctx *c, const double *w, size_t n, int axis, long long *out)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(qs_world_to_grid_kernel, dim3((unsigned int)((n + 255) / 256)), dim3(256), 0, c->stream,
+                       w, n, axis ? c->geom.oy : c->geom.ox, c->geom.res, out);
+    return hipGetLastError();
+}

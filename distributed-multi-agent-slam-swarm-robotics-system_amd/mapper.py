@@ -1,0 +1,364 @@
+"""Host-side mirror of the reference mapper's object API over the HIP library.
+
+`QuasarMapper` is the batched equivalent of dual_bot_mapper.py's main() recv loop
+(:815-945): it owns one GPU context and exposes look-alikes of the objects the reference's
+renderer and timers read -- `OccupancyGrid` (:110-237), `PoseGraphSLAM` (:261-338),
+`drift_correction`, `zone_boxes`.  All arithmetic happens in the HIP kernels; this file only
+marshals buffers (numpy <-> C ABI).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import QsConfig, QuasarError, UINT64_MAX, check
+from . import protocol as P
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class QuasarMapper:
+    """One mapper instance on one GPU.  Defaults are the reference's constants."""
+
+    def __init__(self, size=P.GRID_SIZE, resolution=P.GRID_RESOLUTION, origin_x=P.GRID_ORIGIN_X,
+                 origin_y=P.GRID_ORIGIN_Y, separation=0.0, max_agent=2, bots_per_graph=0,
+                 enable_counts=True, enable_ekf=False, device=0, raycast_mode=0,
+                 ekf_metres_per_tick=0.0107, min_poses_between=P.MIN_POSES_BETWEEN,
+                 closure_radius=P.CLOSURE_RADIUS, closure_correction=P.CLOSURE_CORRECTION):
+        self._L = _lib.load()
+        cfg = QsConfig()
+        check(None, self._L.qs_config_default(C.byref(cfg)), "qs_config_default")
+        cfg.size, cfg.res, cfg.ox, cfg.oy = size, resolution, origin_x, origin_y
+        cfg.separation = separation
+        cfg.max_agent, cfg.bots_per_graph = max_agent, bots_per_graph
+        cfg.enable_counts, cfg.enable_ekf = int(enable_counts), int(enable_ekf)
+        cfg.device, cfg.raycast_mode = device, raycast_mode
+        cfg.ekf_metres_per_tick = ekf_metres_per_tick
+        cfg.min_poses_between = min_poses_between
+        cfg.closure_radius, cfg.closure_correction = closure_radius, closure_correction
+        self.cfg = cfg
+        self.size, self.res, self.ox, self.oy = size, resolution, origin_x, origin_y
+        self.max_agent = max_agent
+        self.bots_per_graph = bots_per_graph if bots_per_graph > 0 else max_agent
+        self.n_graphs = (max_agent + self.bots_per_graph - 1) // self.bots_per_graph
+        h = C.c_void_p()
+        rc = self._L.qs_create(C.byref(cfg), C.byref(h))
+        if rc != 0:
+            raise QuasarError(f"qs_create failed ({rc}): {self._L.qs_last_error(None).decode()}")
+        self._h = h
+        self._last_n = 0
+        self.occ_grid = OccupancyGrid._attached(self)
+        self.slam = PoseGraphSLAM._attached(self)
+
+    # -- lifetime ---------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.qs_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _chk(self, rc, what):
+        check(self._h, rc, what)
+
+    def reset(self):
+        self._chk(self._L.qs_reset(self._h), "qs_reset")
+
+    def sync(self):
+        self._chk(self._L.qs_sync(self._h), "qs_sync")
+
+    def set_stream(self, hip_stream_ptr):
+        self._chk(self._L.qs_set_stream(self._h, C.c_void_p(hip_stream_ptr)), "qs_set_stream")
+
+    def set_bot_offset(self, bot, off_x):
+        self._chk(self._L.qs_set_bot_offset(self._h, bot, off_x), "qs_set_bot_offset")
+
+    # -- ingest: dual_bot_mapper.py:826-919 ---------------------------------------------------
+    def ingest(self, datagrams, recv_time=None, seq0=None):
+        """datagrams: list of bytes objects (any lengths), in arrival order."""
+        if len(datagrams) == 0:
+            return 0
+        if all(len(d) == P.PACKET_SIZE for d in datagrams):
+            buf = np.frombuffer(b"".join(datagrams), dtype=np.uint8).reshape(-1, P.PACKET_SIZE)
+            return self.ingest_array(buf, None, recv_time, seq0)
+        buf, lens = P.pack_datagrams(datagrams)
+        return self.ingest_array(buf, lens, recv_time, seq0)
+
+    def ingest_array(self, buf, lengths=None, recv_time=None, seq0=None):
+        """buf: uint8 [n, stride] host array; lengths: uint16 [n] or None."""
+        buf = np.ascontiguousarray(buf, dtype=np.uint8)
+        if buf.ndim != 2:
+            raise ValueError("buf must be [n, stride]")
+        n, stride = buf.shape
+        lens = None if lengths is None else np.ascontiguousarray(lengths, dtype=np.uint16)
+        t = None if recv_time is None else np.ascontiguousarray(recv_time, dtype=np.float64)
+        if lens is not None and len(lens) != n:
+            raise ValueError("lengths must have one entry per record")
+        if t is not None and len(t) != n:
+            raise ValueError("recv_time must have one entry per record")
+        self._chk(self._L.qs_ingest(self._h, _ptr(buf), n, stride, _ptr(lens), _ptr(t),
+                                    UINT64_MAX if seq0 is None else int(seq0)), "qs_ingest")
+        self._last_n = n
+        return n
+
+    def ingest_device(self, d_pkts, n, stride, d_lens=0, d_time=0, seq0=None):
+        """Device-resident input (raw device addresses as ints); asynchronous."""
+        self._chk(self._L.qs_ingest_device(self._h, C.c_void_p(d_pkts), n, stride,
+                                           C.c_void_p(d_lens) if d_lens else None,
+                                           C.c_void_p(d_time) if d_time else None,
+                                           UINT64_MAX if seq0 is None else int(seq0)), "qs_ingest_device")
+        self._last_n = n
+
+    def last_batch(self):
+        """(accepted uint8 [n], pose float64 [n,3]) of the last ingest (rx, ry, ryaw; :850-857)."""
+        n = self._last_n
+        acc = np.zeros(n, dtype=np.uint8)
+        pose = np.zeros((n, 3), dtype=np.float64)
+        self._chk(self._L.qs_last_batch(self._h, _ptr(acc), _ptr(pose), n), "qs_last_batch")
+        return acc, pose
+
+    def last_hits(self):
+        """(xy float64 [n,4,2], valid uint8 [n,4]) of the last ingest: point_clouds appends (:892)."""
+        n = self._last_n
+        xy = np.zeros((n, 4, 2), dtype=np.float64)
+        valid = np.zeros((n, 4), dtype=np.uint8)
+        self._chk(self._L.qs_last_hits(self._h, _ptr(xy), _ptr(valid), n), "qs_last_hits")
+        return xy, valid
+
+    # -- grid ---------------------------------------------------------------------------------
+    def grid_i8(self):
+        out = np.empty((self.size, self.size), dtype=np.int8)
+        self._chk(self._L.qs_grid_i8(self._h, _ptr(out)), "qs_grid_i8")
+        return out
+
+    def grid_i8_device(self, d_out):
+        self._chk(self._L.qs_grid_i8_device(self._h, C.c_void_p(d_out)), "qs_grid_i8_device")
+
+    def counts(self):
+        hits = np.empty((self.size, self.size), dtype=np.int32)
+        misses = np.empty((self.size, self.size), dtype=np.int32)
+        self._chk(self._L.qs_grid_counts(self._h, _ptr(hits), _ptr(misses)), "qs_grid_counts")
+        return hits, misses
+
+    def logodds(self, l_occ=0.85, l_free=0.4, lmin=-2.0, lmax=3.5):
+        out = np.empty((self.size, self.size), dtype=np.float32)
+        self._chk(self._L.qs_grid_logodds(self._h, l_occ, l_free, lmin, lmax, _ptr(out)), "qs_grid_logodds")
+        return out
+
+    def update_rays(self, rx, ry, hx, hy, valid, seq0=None):
+        a = [np.ascontiguousarray(v, dtype=np.float64) for v in (rx, ry, hx, hy)]
+        v = np.ascontiguousarray(valid, dtype=np.uint8)
+        self._chk(self._L.qs_update_rays(self._h, *[_ptr(x) for x in a], _ptr(v), len(v),
+                                         UINT64_MAX if seq0 is None else int(seq0)), "qs_update_rays")
+
+    def world_to_grid(self, w, axis=0):
+        w = np.ascontiguousarray(w, dtype=np.float64)
+        out = np.empty(len(w), dtype=np.int64)
+        self._chk(self._L.qs_world_to_grid(self._h, _ptr(w), len(w), axis, _ptr(out)), "qs_world_to_grid")
+        return out
+
+    def device_buffers(self):
+        """(stamps_ptr, stamps_bytes, counts_ptr, counts_bytes) raw device addresses."""
+        sp, cp = C.c_void_p(), C.c_void_p()
+        sb, cb = C.c_size_t(), C.c_size_t()
+        self._chk(self._L.qs_device_buffers(self._h, C.byref(sp), C.byref(sb), C.byref(cp), C.byref(cb)),
+                  "qs_device_buffers")
+        return sp.value, sb.value, cp.value or 0, cb.value
+
+    # -- SLAM -----------------------------------------------------------------------------------
+    def slam_sizes(self, graph=0):
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        self._chk(self._L.qs_slam_sizes(self._h, graph, C.byref(a), C.byref(b), C.byref(c)), "qs_slam_sizes")
+        return a.value, b.value, c.value
+
+    def closures(self, graph=0):
+        n = self.slam_sizes(graph)[2]
+        idx = np.zeros((n, 2), dtype=np.int64)
+        corr = np.zeros((n, 2), dtype=np.float64)
+        if n:
+            self._chk(self._L.qs_slam_closures(self._h, graph, _ptr(idx), _ptr(corr), n), "qs_slam_closures")
+        return idx, corr
+
+    def landmarks(self, graph=0):
+        n = self.slam_sizes(graph)[1]
+        xy = np.zeros((n, 2), dtype=np.float64)
+        ti = np.zeros((n, 2), dtype=np.int64)
+        if n:
+            self._chk(self._L.qs_slam_landmarks(self._h, graph, _ptr(xy), _ptr(ti), n), "qs_slam_landmarks")
+        return xy, ti
+
+    def drift(self, bot):
+        out = np.zeros(2, dtype=np.float64)
+        self._chk(self._L.qs_drift(self._h, bot, _ptr(out)), "qs_drift")
+        return out
+
+    @property
+    def drift_correction(self):
+        """dict bot -> (dx, dy), as main()'s drift_correction (:782)."""
+        return {b: tuple(self.drift(b)) for b in range(1, self.max_agent + 1)}
+
+    # -- ZONE -------------------------------------------------------------------------------------
+    def zone(self, bot):
+        out = np.zeros(4, dtype=np.float64)
+        valid = C.c_int32()
+        self._chk(self._L.qs_zone(self._h, bot, _ptr(out), C.byref(valid)), "qs_zone")
+        return tuple(out) if valid.value else None
+
+    def zone_packet(self, bot, online=True) -> bytes:
+        out = np.zeros(P.ZONE_SIZE, dtype=np.uint8)
+        self._chk(self._L.qs_zone_packet(self._h, bot, int(online), _ptr(out)), "qs_zone_packet")
+        return out.tobytes()
+
+    @property
+    def zone_boxes(self):
+        return {b: self.zone(b) for b in range(1, self.max_agent + 1)}
+
+    # -- merge ------------------------------------------------------------------------------------
+    def fuse(self, others):
+        arr = (C.c_void_p * len(others))(*[o._h for o in others])
+        self._chk(self._L.qs_fuse(self._h, arr, len(others)), "qs_fuse")
+
+    def fuse_buffers(self, stamp_ptrs, count_ptrs=None):
+        n = len(stamp_ptrs)
+        sp = (C.c_void_p * n)(*stamp_ptrs)
+        cp = (C.c_void_p * n)(*count_ptrs) if count_ptrs else None
+        self._chk(self._L.qs_fuse_buffers(self._h, sp, cp, n), "qs_fuse_buffers")
+
+    def grid_to_pcd(self, grid, res, ox, oy):
+        """MapMerger.grid_to_pcd (map_merger.py:64-85) -> float64 [n,2] (x, y)."""
+        grid = np.ascontiguousarray(grid, dtype=np.int8)
+        h, w = grid.shape
+        n = C.c_size_t()
+        self._chk(self._L.qs_grid_to_pcd(self._h, _ptr(grid), h, w, res, ox, oy, None, 0, C.byref(n)),
+                  "qs_grid_to_pcd")
+        xy = np.zeros((n.value, 2), dtype=np.float64)
+        if n.value:
+            self._chk(self._L.qs_grid_to_pcd(self._h, _ptr(grid), h, w, res, ox, oy, _ptr(xy), n.value,
+                                             C.byref(n)), "qs_grid_to_pcd")
+        return xy
+
+    def rasterise(self, xy, res):
+        """MapMerger.publish_global_map (map_merger.py:87-127) -> (int8 grid, (min_x, min_y))."""
+        xy = np.ascontiguousarray(xy, dtype=np.float64)
+        dims = np.zeros(2, dtype=np.int32)
+        origin = np.zeros(2, dtype=np.float64)
+        self._chk(self._L.qs_rasterise(self._h, _ptr(xy), len(xy), res, _ptr(dims), _ptr(origin), None),
+                  "qs_rasterise")
+        if len(xy) == 0:
+            return None, None
+        grid = np.empty((int(dims[0]), int(dims[1])), dtype=np.int8)
+        self._chk(self._L.qs_rasterise(self._h, _ptr(xy), len(xy), res, _ptr(dims), _ptr(origin), _ptr(grid)),
+                  "qs_rasterise")
+        return grid, origin
+
+    # -- EKF --------------------------------------------------------------------------------------
+    def ekf_init(self, bot, t, x0):
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        self._chk(self._L.qs_ekf_init(self._h, bot, t, _ptr(x0)), "qs_ekf_init")
+
+    def ekf_step(self, bots, omega_m, t, z_v=None, z_omega=None):
+        b = np.ascontiguousarray(bots, dtype=np.int32)
+        om = np.ascontiguousarray(omega_m, dtype=np.float64)
+        tt = np.ascontiguousarray(t, dtype=np.float64)
+        upd = z_v is not None
+        zv = np.ascontiguousarray(z_v, dtype=np.float64) if upd else None
+        zo = np.ascontiguousarray(z_omega, dtype=np.float64) if upd else None
+        self._chk(self._L.qs_ekf_step(self._h, _ptr(b), _ptr(om), _ptr(tt), _ptr(zv), _ptr(zo), len(b), int(upd)),
+                  "qs_ekf_step")
+
+    def ekf_state(self, bot):
+        x = np.zeros(6, dtype=np.float64)
+        Pm = np.zeros((6, 6), dtype=np.float64)
+        self._chk(self._L.qs_ekf_state(self._h, bot, _ptr(x), _ptr(Pm)), "qs_ekf_state")
+        return x, Pm
+
+    # -- counters / timing ------------------------------------------------------------------------
+    def counters(self):
+        out = np.zeros(len(_lib.QS_CNT_NAMES), dtype=np.uint64)
+        self._chk(self._L.qs_counters(self._h, _ptr(out)), "qs_counters")
+        return dict(zip(_lib.QS_CNT_NAMES, (int(v) for v in out)))
+
+    def timing_enable(self, on=True):
+        self._chk(self._L.qs_timing_enable(self._h, int(on)), "qs_timing_enable")
+
+    def stage_times(self, reset=True):
+        ms = np.zeros(len(_lib.QS_STAGE_NAMES), dtype=np.float64)
+        ln = np.zeros(len(_lib.QS_STAGE_NAMES), dtype=np.uint64)
+        self._chk(self._L.qs_stage_times(self._h, _ptr(ms), _ptr(ln), int(reset)), "qs_stage_times")
+        return {k: (float(m), int(c)) for k, m, c in zip(_lib.QS_STAGE_NAMES, ms, ln)}
+
+
+class OccupancyGrid:
+    """Look-alike of dual_bot_mapper.py::OccupancyGrid (:110-237) backed by the device grid.
+    `.grid` is synchronised from the GPU on access; attribute names match what MapRenderer
+    reads (:494-512)."""
+
+    def __init__(self, size=P.GRID_SIZE, resolution=P.GRID_RESOLUTION,
+                 origin_x=P.GRID_ORIGIN_X, origin_y=P.GRID_ORIGIN_Y, device=0):
+        m = QuasarMapper(size, resolution, origin_x, origin_y, device=device)
+        self._m = m
+        self.size, self.res, self.ox, self.oy = size, resolution, origin_x, origin_y
+
+    @classmethod
+    def _attached(cls, mapper):
+        g = cls.__new__(cls)
+        g._m = mapper
+        g.size, g.res, g.ox, g.oy = mapper.size, mapper.res, mapper.ox, mapper.oy
+        return g
+
+    @property
+    def grid(self):
+        return self._m.grid_i8()
+
+    def world_to_grid(self, wx, wy):                      # :121-125
+        gx = int((wx - self.ox) / self.res)
+        gy = int((wy - self.oy) / self.res)
+        return gx, gy
+
+    def grid_to_world(self, gx, gy):                      # :127-131
+        return self.ox + (gx + 0.5) * self.res, self.oy + (gy + 0.5) * self.res
+
+    def in_bounds(self, gx, gy):                          # :133-134
+        return 0 <= gx < self.size and 0 <= gy < self.size
+
+    def update_ray(self, robot_x, robot_y, hit_x, hit_y, hit_valid):   # :136-156
+        self._m.update_rays([robot_x], [robot_y], [hit_x], [hit_y], [1 if hit_valid else 0])
+
+    def update_rays(self, robot_x, robot_y, hit_x, hit_y, hit_valid):
+        self._m.update_rays(robot_x, robot_y, hit_x, hit_y, hit_valid)
+
+
+class PoseGraphSLAM:
+    """Read view of the device pose graph with the reference's attribute names (:267-271)."""
+
+    @classmethod
+    def _attached(cls, mapper, graph=0):
+        s = cls.__new__(cls)
+        s._m, s._g = mapper, graph
+        return s
+
+    @property
+    def closures(self):
+        idx, corr = self._m.closures(self._g)
+        return [(int(i[0]), int(i[1]), float(c[0]), float(c[1])) for i, c in zip(idx, corr)]
+
+    @property
+    def landmarks(self):
+        xy, ti = self._m.landmarks(self._g)
+        return [(float(p[0]), float(p[1]), int(t[0]), int(t[1])) for p, t in zip(xy, ti)]
+
+    @property
+    def n_nodes(self):
+        return self._m.slam_sizes(self._g)[0]

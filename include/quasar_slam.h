@@ -1,0 +1,169 @@
+/*
+ * quasar_slam.h -- C ABI of the MI355X-native central-mapper hot path.
+ *
+ * The reference (deevinandu/Distributed-Multi-Agent-SLAM-Swarm-Robotics-System) has no
+ * FFI: its boundary is the Python object API used by server_nodes/dual_bot_mapper.py's
+ * main() and MapRenderer.  Every entry point below names the reference interface it
+ * replaces (file:line, relative to the reference tree).  INTEGRATION.md shows the ctypes
+ * binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every call returns 0 on success, <0 on error (QS_E_*); qs_last_error() gives text;
+ *   - one context = one GPU = one mapper instance; calls on one context are serialised by
+ *     the caller (the reference is single-threaded); contexts are independent;
+ *   - the caller owns every buffer it passes; the library owns all device state;
+ *   - "host" pointers are ordinary memory, "device" pointers are HIP device memory on the
+ *     context's GPU; work is enqueued on the context's stream and host-visible results are
+ *     complete when the call returns (device variants: after qs_sync()).
+ */
+#ifndef QUASAR_SLAM_H
+#define QUASAR_SLAM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QS_OK 0
+#define QS_E_INVAL (-1)    /* bad argument */
+#define QS_E_HIP (-2)      /* HIP runtime error (text in qs_last_error) */
+#define QS_E_NOMEM (-3)
+#define QS_E_RANGE (-4)    /* index (bot, graph, capacity) out of range */
+#define QS_E_NODEV (-5)    /* no usable GPU */
+
+/* wire formats: dual_bot_mapper.py:41-54 */
+#define QS_PACKET_SIZE 42     /* QuasarPacket v2 '<4sBfffiIffffB' */
+#define QS_PACKET_SIZE_V1 41  /* QuasarPacket v1 '<4sBfffiIffff'  */
+#define QS_ZONE_SIZE 20       /* ZONE '<4sffff' */
+
+typedef struct qs_ctx qs_ctx;
+
+typedef struct qs_config {
+    /* OccupancyGrid(size, resolution, origin_x, origin_y)  dual_bot_mapper.py:113-119 */
+    int32_t size;
+    double res, ox, oy;
+    double separation;          /* --separation, added to bot 2's x   :715, :851-852 */
+    double min_dist, max_dist;  /* MIN_DIST_M, MAX_DIST_M            :57-58  */
+    double closure_radius;      /* CLOSURE_RADIUS                     :97  */
+    int32_t min_poses_between;  /* MIN_POSES_BETWEEN                  :98  */
+    double closure_correction;  /* CLOSURE_CORRECTION                 :99  */
+    int32_t max_agent;          /* accept agent_id 1..max_agent; reference: 2 (:842) */
+    int32_t bots_per_graph;     /* bots sharing one PoseGraphSLAM; 0 = all (reference) */
+    int32_t enable_counts;      /* keep per-cell hit/miss counters (build extension) */
+    int32_t enable_ekf;         /* run the firmware EKF per bot on ingest (ekf.cpp) */
+    double ekf_metres_per_tick; /* encoder scale for the EKF wiring (generator: 0.0107) */
+    int32_t device;             /* HIP device ordinal */
+    int32_t raycast_mode;       /* 0 = auto, 1 = direct global atomics, 2 = LDS tile-binned */
+    int32_t reserved[7];
+} qs_config;
+
+/* reference constants (dual_bot_mapper.py:57-99) */
+int qs_config_default(qs_config *cfg);
+
+int qs_create(const qs_config *cfg, qs_ctx **out);
+int qs_destroy(qs_ctx *ctx);
+const char *qs_last_error(const qs_ctx *ctx);   /* ctx may be NULL: last create error */
+/* run on the caller's hipStream_t (e.g. torch's current stream); NULL = own stream */
+int qs_set_stream(qs_ctx *ctx, void *hip_stream);
+int qs_sync(qs_ctx *ctx);
+/* new session: grid -> UNKNOWN, pose graphs, drift, zones, EKF cleared (main() start, :755-785) */
+int qs_reset(qs_ctx *ctx);
+/* per-bot x offset; bot 2 defaults to cfg.separation (:851-852) */
+int qs_set_bot_offset(qs_ctx *ctx, int32_t bot, double off_x);
+
+/* ---- ingest: the batched body of the recv loop, dual_bot_mapper.py:826-919 ------------
+ * n datagrams, record i at pkts + i*stride, its length lens[i] (NULL: every length ==
+ * stride).  42-byte v2 and 41-byte v1 records are decoded, anything else, a bad magic or
+ * an agent outside 1..max_agent is dropped (:826-843).  recv_time (seconds, may be NULL)
+ * feeds only the EKF wiring.  seq0 = arrival index of record 0 in the global stream
+ * (UINT64_MAX: continue this context's own counter); later records win grid cells. */
+int qs_ingest(qs_ctx *ctx, const uint8_t *pkts, size_t n, size_t stride,
+              const uint16_t *lens, const double *recv_time, uint64_t seq0);
+/* same with device-resident inputs; asynchronous on the context's stream */
+int qs_ingest_device(qs_ctx *ctx, const uint8_t *d_pkts, size_t n, size_t stride,
+                     const uint16_t *d_lens, const double *d_recv_time, uint64_t seq0);
+/* per record of the LAST ingest: accepted flag and pose after offset+drift (:850-857) */
+int qs_last_batch(qs_ctx *ctx, uint8_t *accepted, double *pose_xyyaw /* n x 3 */, size_t n);
+/* valid hit points of the LAST ingest (point_clouds[agent][sensor].append, :892):
+ * 4 slots per record in sensor order front,left,back,right; valid[i*4+s] marks used slots */
+int qs_last_hits(qs_ctx *ctx, double *xy /* n x 4 x 2 */, uint8_t *valid /* n x 4 */, size_t n);
+
+/* ---- OccupancyGrid object API ----------------------------------------------------------
+ * batched OccupancyGrid.update_ray(robot_x, robot_y, hit_x, hit_y, hit_valid)  :136-156 */
+int qs_update_rays(qs_ctx *ctx, const double *rx, const double *ry, const double *hx,
+                   const double *hy, const uint8_t *valid, size_t n, uint64_t seq0);
+/* OccupancyGrid.world_to_grid  :121-125 (device evaluation of the same fp64 expression) */
+int qs_world_to_grid(qs_ctx *ctx, const double *w, size_t n, int32_t axis, int64_t *out);
+/* OccupancyGrid.grid: int8 [size][size], row = gy, values -1/0/100  :92-94, :119 */
+int qs_grid_i8(qs_ctx *ctx, int8_t *out_host);
+int qs_grid_i8_device(qs_ctx *ctx, int8_t *out_dev);
+/* build extension: per-cell counts of OCCUPIED / FREE writes, and a log-odds view
+ * clamp(hits*l_occ - misses*l_free, lmin, lmax) */
+int qs_grid_counts(qs_ctx *ctx, int32_t *hits_host, int32_t *misses_host);
+int qs_grid_logodds(qs_ctx *ctx, float l_occ, float l_free, float lmin, float lmax,
+                    float *out_host);
+/* raw device state, for collectives (RCCL all-reduce MAX on int32 stamps, SUM on counts) */
+int qs_device_buffers(qs_ctx *ctx, void **stamps_dev, size_t *stamps_bytes,
+                      void **counts_dev, size_t *counts_bytes);
+
+/* ---- PoseGraphSLAM state  dual_bot_mapper.py:261-338 ---------------------------------- */
+int qs_slam_sizes(qs_ctx *ctx, int32_t graph, int64_t *n_nodes, int64_t *n_landmarks,
+                  int64_t *n_closures);
+/* slam.closures: (lm_idx, node_idx), (corr_dx, corr_dy)  :270, :317 */
+int qs_slam_closures(qs_ctx *ctx, int32_t graph, int64_t *idx2, double *corr2, size_t cap);
+/* slam.landmarks: (x, y), (type, node_idx) in insertion order  :269, :288 */
+int qs_slam_landmarks(qs_ctx *ctx, int32_t graph, double *xy, int64_t *type_idx, size_t cap);
+/* drift_correction[bot]  :782, :910-914 */
+int qs_drift(qs_ctx *ctx, int32_t bot, double out[2]);
+
+/* ---- ZONE output  dual_bot_mapper.py:675-688, :702-706, :922-945 ----------------------- */
+/* bbox over bot's valid hit points U path; *valid = 0 when the bot has no points yet */
+int qs_zone(qs_ctx *ctx, int32_t bot, double out[4], int32_t *valid);
+/* the 20-byte datagram sent to the OTHER bot; online == 0 lifts the zone (999,999,-999,-999) */
+int qs_zone_packet(qs_ctx *ctx, int32_t bot, int32_t online, uint8_t out[QS_ZONE_SIZE]);
+
+/* ---- grid merge ------------------------------------------------------------------------
+ * shared-grid semantics of dual_bot_mapper.py:785: dst <- fuse(dst, srcs...) cell-wise
+ * (latest stamp wins, counts add).  All contexts on dst's GPU, same geometry. */
+int qs_fuse(qs_ctx *dst, qs_ctx *const *srcs, size_t n);
+/* same over raw device buffers (e.g. peers' grids gathered by the caller) */
+int qs_fuse_buffers(qs_ctx *dst, const void *const *stamps_dev, const void *const *counts_dev,
+                    size_t n);
+/* MapMerger.grid_to_pcd  server_nodes/map_merger.py:64-85: cells > 50 -> (col*res+ox,
+ * row*res+oy) in row-major order.  grid: host int8 [h][w]; returns the count in *n_out. */
+int qs_grid_to_pcd(qs_ctx *ctx, const int8_t *grid, int32_t h, int32_t w, double res,
+                   double ox, double oy, double *xy, size_t cap, size_t *n_out);
+/* MapMerger.publish_global_map  map_merger.py:87-127: points -> int8 canvas; call with
+ * grid == NULL to obtain dims {h,w} and origin {min_x,min_y} first */
+int qs_rasterise(qs_ctx *ctx, const double *xy, size_t n, double res, int32_t dims[2],
+                 double origin[2], int8_t *grid);
+
+/* ---- EKF  AgentFirmware_Bot1/ekf.cpp:5-92 ---------------------------------------------- */
+/* batched over bots: for k in 0..n: predict(omega_m[k], t[k]) then update(z_v[k], z_omega[k])
+ * on bot_ids[k] (each bot at most once per call); do_update == 0: predict only */
+int qs_ekf_init(qs_ctx *ctx, int32_t bot, double t, const double x0[6]);
+int qs_ekf_step(qs_ctx *ctx, const int32_t *bot_ids, const double *omega_m, const double *t,
+                const double *z_v, const double *z_omega, size_t n, int32_t do_update);
+int qs_ekf_state(qs_ctx *ctx, int32_t bot, double x[6], double P[36]);
+
+/* ---- counters / timing ------------------------------------------------------------------ */
+enum { QS_CNT_DATAGRAMS = 0, QS_CNT_ACCEPTED, QS_CNT_RAYS, QS_CNT_CELLS, QS_CNT_HITS,
+       QS_CNT_CLOSURES, QS_CNT_LANDMARKS, QS_CNT_REBASES, QS_CNT_N };
+int qs_counters(qs_ctx *ctx, uint64_t out[QS_CNT_N]);
+/* HIP-event timing of the pipeline stages on the context's stream.  enable != 0 brackets
+ * each stage of every ingest with events; qs_stage_times returns accumulated ms and the
+ * launch count per stage since the last call with reset != 0. */
+enum { QS_STAGE_DECODE = 0, QS_STAGE_SLAM, QS_STAGE_RAYCAST, QS_STAGE_EKF, QS_STAGE_BIN,
+       QS_STAGE_N };
+int qs_timing_enable(qs_ctx *ctx, int32_t enable);
+int qs_stage_times(qs_ctx *ctx, double ms[QS_STAGE_N], uint64_t launches[QS_STAGE_N],
+                   int32_t reset);
+
+const char *qs_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QUASAR_SLAM_H */
