@@ -1,0 +1,167 @@
+#!/usr/bin/env python3
+"""bench.py -- QuasarPackets/s into a 4096x4096 occupancy grid on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path over one batch of synthetic input, from a fresh session:
+    qs_reset -> decode (K0) -> landmark loop closure / drift (K4) -> 4-ray raycast into the
+    grid (K1) [-> per-bot EKF (K5)] [-> RCCL all-reduce of the grids when N > 1].
+Workload at N=1: BASELINE.json configs[1] -- the 2-bot generate_fake_dual_session.py session
+(tests/golden/session_telemetry.csv, produced by the reference generator) cycled to B packets,
+4096^2 grid, res 0.05, origin -102.4.  N > 1: every rank runs that stream for its own two bots
+in its own room tile (weak scaling, shard by agent), stamps carry the global arrival index
+(seq = base + i*N + rank) and one all-reduce (MAX on stamps, SUM on counts) per step fuses the
+per-GPU grids.  Inputs are resident in HBM before the timed region.
+
+Prints ONE JSON line (rank 0) with the driver's contract plus `roofline` and `cpu_baseline`.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+PKG = "distributed-multi-agent-slam-swarm-robotics-system_amd"
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=1 << 20, help="packets per step per GPU")
+    ap.add_argument("--grid", type=int, default=4096)
+    ap.add_argument("--raycast-mode", type=int, default=0)
+    ap.add_argument("--no-counts", action="store_true", help="tri-state stamps only (no hit/miss counters)")
+    ap.add_argument("--ekf", type=int, default=1, help="run the per-bot EKF stage (1) or not (0)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=200000, help="packets of the same stream timed on the CPU")
+    return ap.parse_args()
+
+
+def cpu_baseline(stream, grid, sample):
+    """The oracle (C restatement of the reference path, 1 thread) on a bounded prefix of the
+    same stream.  Reported, never the thing shipped."""
+    from oracle import oracle as orc
+    n = min(sample, len(stream))
+    half = grid * 0.05 / 2
+    m = orc.OracleMapper(grid, 0.05, -half, -half, 0.0, max_agent=2)
+    t0 = time.perf_counter()
+    m.feed_stream(stream[:n])
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "packets/s", "cores": 1, "kind": "port",
+            "sample": f"first {n} packets of the same stream, oracle/oracle.c (gcc -O2), {dt:.2f} s, "
+                      f"host has {os.cpu_count()} logical CPUs"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    pkg = importlib.import_module(PKG)
+    replay = importlib.import_module(PKG + ".replay")
+    distmod = importlib.import_module(PKG + ".dist")
+
+    B, G = args.batch, args.grid
+    half = G * 0.05 / 2
+    session, _ = replay.telemetry_csv_to_packets()
+    stream = replay.cycle_stream(session, B)
+    if world > 1:   # this rank's two bots live in their own room tile (8 m pitch)
+        rec = stream.view(pkg.protocol.PACKET_DTYPE).reshape(-1)
+        rec["x"] = (rec["x"].astype(np.float64) + 8.0 * (rank % 8) - 28.0).astype(np.float32)
+        rec["y"] = (rec["y"].astype(np.float64) + 8.0 * (rank // 8)).astype(np.float32)
+    d_stream = torch.from_numpy(stream).to(dev)               # resident in HBM before timing
+    d_time = torch.arange(B, dtype=torch.float64, device=dev) * 0.25
+    torch.cuda.synchronize()
+
+    m = pkg.QuasarMapper(G, 0.05, -half, -half, max_agent=2, enable_counts=not args.no_counts,
+                         enable_ekf=bool(args.ekf), device=local_rank, raycast_mode=args.raycast_mode,
+                         seq_stride=world)
+    stream_t = torch.cuda.current_stream()
+    m.set_stream(stream_t.cuda_stream)
+
+    def step(k):
+        m.reset()
+        m.ingest_device(d_stream.data_ptr(), B, 42, 0, d_time.data_ptr(), seq0=rank)
+        if world > 1:
+            distmod.allreduce_grids(m, dev, counts=not args.no_counts)
+
+    for k in range(args.warmup):
+        step(k)
+    torch.cuda.synchronize()
+    m.stage_times(reset=True)
+    m.timing_enable(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(k)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    m.timing_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    stages = m.stage_times(reset=True)
+    cnt = m.counters()                       # counters of the last step (reset every step)
+    per_cell = 8 + (0 if args.no_counts else 8)
+    alg_bytes = 42 * cnt["datagrams"] + cnt["cells"] * per_cell
+    ray_ms, ray_n = stages["raycast"]
+    ray_avg_s = (ray_ms / max(ray_n, 1)) * 1e-3
+    achieved = alg_bytes / ray_avg_s / 1e9 if ray_avg_s > 0 else 0.0
+
+    if rank == 0:
+        out = {
+            "metric": "QuasarPackets/sec into 4096^2 grid",
+            "value": world * B * args.steps / elapsed,
+            "unit": "packets/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64 pose/trig + u32 stamps",
+            "data": "synthetic: reference generator's 2-bot session cycled",
+            "config": {"workload": f"configs[1]: 2-bot stream, {G}x{G} grid, res 0.05, {B} packets/step/GPU, "
+                                   f"fresh session per step, decode+loop-closure+raycast"
+                                   f"{'+EKF' if args.ekf else ''}{'+allreduce' if world > 1 else ''}",
+                       "batch": B, "grid": G, "counts": not args.no_counts, "ekf": bool(args.ekf),
+                       "raycast_mode": args.raycast_mode, "sharding": f"by agent, {world} x 2 bots"},
+            "stages_ms_per_step": {k: (v[0] / max(v[1], 1)) for k, v in stages.items() if v[1]},
+            "counters_per_step": cnt,
+            "roofline": {"bound": "hbm", "kernel": "raycast (K1)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "avg_launch_ms": ray_avg_s * 1e3},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(stream, G, args.cpu_sample)
+        print(json.dumps(out))
+    m.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

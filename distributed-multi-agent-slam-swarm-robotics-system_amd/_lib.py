@@ -34,7 +34,8 @@ class QsConfig(C.Structure):
         ("ekf_metres_per_tick", C.c_double),
         ("device", C.c_int32),
         ("raycast_mode", C.c_int32),
-        ("reserved", C.c_int32 * 7),
+        ("seq_stride", C.c_int32),
+        ("reserved", C.c_int32 * 6),
     ]
 
 

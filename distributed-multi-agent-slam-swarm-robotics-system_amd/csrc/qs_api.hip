@@ -372,7 +372,9 @@ static int ingest_device(qs_ctx *c, const uint8_t *d_pkts, size_t n, size_t stri
     int rc = ensure_batch(c, n);
     if (rc != QS_OK) return rc;
     c->b.n = n;
-    rc = ensure_epoch(c, seq0, n);
+    const uint64_t sstride = c->cfg.seq_stride > 0 ? (uint64_t)c->cfg.seq_stride : 1;
+    // epoch decisions use the stride-aligned range so that all ranks of a sharded stream agree
+    rc = ensure_epoch(c, seq0 - seq0 % sstride, n * sstride);
     if (rc != QS_OK) return rc;
     HIPCHK(c, hipMemsetAsync(c->d_graph_batch, 0, (size_t)c->n_graphs * 2 * sizeof(unsigned long long), c->stream));
     { StageTimer t(c, QS_STAGE_DECODE); HIPCHK(c, qs_launch_decode(c, d_pkts, n, stride, d_lens)); t.stop(); }
@@ -381,12 +383,12 @@ static int ingest_device(qs_ctx *c, const uint8_t *d_pkts, size_t n, size_t stri
     { StageTimer t(c, QS_STAGE_SLAM); HIPCHK(c, qs_launch_slam(c, n)); t.stop(); }
     {
         StageTimer t(c, QS_STAGE_RAYCAST);
-        if (c->cfg.raycast_mode == 2) HIPCHK(c, qs_launch_raycast_tiled(c, n, seq0));
-        else HIPCHK(c, qs_launch_raycast_direct(c, n, seq0));
+        if (c->cfg.raycast_mode == 1) HIPCHK(c, qs_launch_raycast_direct(c, n, seq0));
+        else HIPCHK(c, qs_launch_raycast_tiled(c, n, seq0));      // 0 (auto) and 2
         t.stop();
     }
     if (c->cfg.enable_ekf) { StageTimer t(c, QS_STAGE_EKF); HIPCHK(c, qs_launch_ekf_ingest(c, n, d_time)); t.stop(); }
-    c->next_seq = seq0 + n;
+    c->next_seq = seq0 + n * sstride;
     return QS_OK;
 }
 

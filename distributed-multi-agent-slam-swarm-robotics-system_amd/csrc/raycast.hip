@@ -19,7 +19,7 @@ template <bool COUNTS>
 __global__ void __launch_bounds__(RC_BLOCK)
 qs_raycast_direct_kernel(size_t n, QsBatch b, QsGeom geo, unsigned int *__restrict__ stamps,
                          unsigned long long *__restrict__ counts, unsigned long long ord_base,
-                         unsigned long long *__restrict__ zone, int max_agent,
+                         unsigned long long ord_stride, unsigned long long *__restrict__ zone, int max_agent,
                          unsigned long long *__restrict__ counters)
 {
     __shared__ unsigned long long s_zone[QS_MAX_AGENT + 1][4];
@@ -54,7 +54,7 @@ qs_raycast_direct_kernel(size_t n, QsBatch b, QsGeom geo, unsigned int *__restri
             my_hit = 1;
         }
         my_ray = 1;
-        const unsigned int key_free = (unsigned int)((ord_base + 4ull * i + s + 1) << 1);
+        const unsigned int key_free = (unsigned int)((ord_base + ord_stride * i + s + 1) << 1);
         QsLine ln;
         if (qs_line_setup(ray, rx, ry, geo, ln)) {
             int x = ln.x0, y = ln.y0, err = ln.dx - ln.dy;
@@ -96,13 +96,14 @@ hipError_t qs_launch_raycast_direct(qs_ctx *c, size_t n, uint64_t seq0)
     if (n == 0) return hipSuccess;
     const unsigned int blocks = (unsigned int)((4 * n + RC_BLOCK - 1) / RC_BLOCK);
     const unsigned long long ord_base = 4ull * (seq0 - c->epoch_base);
+    const unsigned long long ord_stride = 4ull * (unsigned long long)(c->cfg.seq_stride > 0 ? c->cfg.seq_stride : 1);
     if (c->cfg.enable_counts)
         hipLaunchKernelGGL(qs_raycast_direct_kernel<true>, dim3(blocks), dim3(RC_BLOCK), 0, c->stream, n,
-                           c->b, c->geom, c->d_stamps, c->d_counts, ord_base, c->d_zone,
+                           c->b, c->geom, c->d_stamps, c->d_counts, ord_base, ord_stride, c->d_zone,
                            c->cfg.max_agent, c->d_counters);
     else
         hipLaunchKernelGGL(qs_raycast_direct_kernel<false>, dim3(blocks), dim3(RC_BLOCK), 0, c->stream, n,
-                           c->b, c->geom, c->d_stamps, c->d_counts, ord_base, c->d_zone,
+                           c->b, c->geom, c->d_stamps, c->d_counts, ord_base, ord_stride, c->d_zone,
                            c->cfg.max_agent, c->d_counters);
     return hipGetLastError();
 }

@@ -26,7 +26,8 @@ class QuasarMapper:
                  origin_y=P.GRID_ORIGIN_Y, separation=0.0, max_agent=2, bots_per_graph=0,
                  enable_counts=True, enable_ekf=False, device=0, raycast_mode=0,
                  ekf_metres_per_tick=0.0107, min_poses_between=P.MIN_POSES_BETWEEN,
-                 closure_radius=P.CLOSURE_RADIUS, closure_correction=P.CLOSURE_CORRECTION):
+                 closure_radius=P.CLOSURE_RADIUS, closure_correction=P.CLOSURE_CORRECTION,
+                 seq_stride=1):
         self._L = _lib.load()
         cfg = QsConfig()
         check(None, self._L.qs_config_default(C.byref(cfg)), "qs_config_default")
@@ -38,6 +39,7 @@ class QuasarMapper:
         cfg.ekf_metres_per_tick = ekf_metres_per_tick
         cfg.min_poses_between = min_poses_between
         cfg.closure_radius, cfg.closure_correction = closure_radius, closure_correction
+        cfg.seq_stride = seq_stride
         self.cfg = cfg
         self.size, self.res, self.ox, self.oy = size, resolution, origin_x, origin_y
         self.max_agent = max_agent

@@ -1,0 +1,72 @@
+"""Replay harness: telemetry CSV -> QuasarPacket bytes, and the synthetic streams of
+BASELINE.json's configs.
+
+The reference has no replay-into-mapper tool (simulation_tools/playback_dual_session.py renders
+the CSVs itself), so this is the build's own: it turns a `telemetry.csv` written by
+simulation_tools/generate_fake_dual_session.py (schema: :369-370 / dual_bot_mapper.py:733-734)
+back into the 42-byte datagrams the bots would have sent (AgentFirmware_Bot1.ino:172-185).
+Host-side numpy only.
+"""
+import csv
+import os
+
+import numpy as np
+
+from . import protocol as P
+
+SESSION_CSV = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                           "tests", "golden", "session_telemetry.csv")
+
+
+def telemetry_csv_to_packets(path=SESSION_CSV):
+    """Rows in FILE order -> (uint8 [n,42], recv_time float64 [n]).  Field conversions follow the
+    firmware's units: yaw degrees -> radians, centimetres -> metres, all stored as f32."""
+    with open(path, newline="") as f:
+        rows = list(csv.DictReader(f))
+    col = lambda k, t: np.array([t(r[k]) for r in rows])
+    pk = P.pack_packets(
+        col("agent", int), col("x", float), col("y", float), np.radians(col("yaw_deg", float)),
+        col("encoder", int), col("v2v", int),
+        np.stack([col("front_cm", float) / 100.0, col("left_cm", float) / 100.0,
+                  col("back_cm", float) / 100.0, col("right_cm", float) / 100.0], axis=1),
+        col("landmark", int))
+    return pk, col("time", float)
+
+
+def cycle_stream(pkts, n):
+    """config C2: the 2-bot session repeated (per-lap world offset 0) up to n packets."""
+    reps = -(-n // len(pkts))
+    return np.ascontiguousarray(np.tile(pkts, (reps, 1))[:n])
+
+
+def multi_bot_stream(pkts, n_bots, n, pitch=8.0, tiles_per_row=25, origin=(-98.0, -98.0), lap_shift=37):
+    """configs C3/C4 (build-defined; the reference has no >2-bot generator): bot i (agent id
+    i+1) lives in its own room tile on a `pitch`-metre lattice and replays the session's bot-1
+    (even i) or bot-2 (odd i) packets, started `lap_shift*i` packets into the lap; streams are
+    interleaved round-robin, n packets in total."""
+    rec = pkts.view(P.PACKET_DTYPE).reshape(-1)
+    lanes = [rec[rec["agent"] == 1], rec[rec["agent"] == 2]]
+    per_bot = -(-n // n_bots)
+    out = np.zeros((per_bot, n_bots), dtype=P.PACKET_DTYPE)
+    for i in range(n_bots):
+        src = lanes[i & 1]
+        idx = (np.arange(per_bot) + lap_shift * i) % len(src)
+        r = src[idx].copy()
+        tx = origin[0] + pitch * (i % tiles_per_row)
+        ty = origin[1] + pitch * (i // tiles_per_row)
+        r["x"] = (r["x"].astype(np.float64) + tx).astype(np.float32)
+        r["y"] = (r["y"].astype(np.float64) + ty).astype(np.float32)
+        r["agent"] = i + 1
+        out[:, i] = r
+    flat = out.reshape(-1)[:n]
+    return np.ascontiguousarray(flat.view(np.uint8).reshape(n, P.PACKET_SIZE))
+
+
+def adversarial_stream(n, seed=1234, lo=-100.0, hi=100.0, max_agent=2):
+    """Uniform-random poses, yaw, distances; landmark types drawn from the session histogram
+    {0:555, 5:128, 3:3, 2:1}: the worst-case-locality stream of SURVEY.md 8(d) D2."""
+    rng = np.random.default_rng(seed)
+    lm = rng.choice(np.array([0, 5, 3, 2], dtype=np.uint8), size=n, p=np.array([555, 128, 3, 1]) / 687.0)
+    return P.pack_packets(rng.integers(1, max_agent + 1, n), rng.uniform(lo, hi, n), rng.uniform(lo, hi, n),
+                          rng.uniform(-np.pi, np.pi, n), np.arange(n), rng.integers(0, 1000, n),
+                          rng.uniform(0.02, 2.5, (n, 4)), lm)

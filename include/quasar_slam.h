@@ -56,7 +56,9 @@ typedef struct qs_config {
     double ekf_metres_per_tick; /* encoder scale for the EKF wiring (generator: 0.0107) */
     int32_t device;             /* HIP device ordinal */
     int32_t raycast_mode;       /* 0 = auto, 1 = direct global atomics, 2 = LDS tile-binned */
-    int32_t reserved[7];
+    int32_t seq_stride;         /* arrival index of record i = seq0 + i*seq_stride (0 = 1); a rank of an
+                                   N-way round-robin sharded stream uses seq0 = base + rank, stride N */
+    int32_t reserved[6];
 } qs_config;
 
 /* reference constants (dual_bot_mapper.py:57-99) */
