@@ -15,10 +15,11 @@ __global__ void __launch_bounds__(DEC_BLOCK)
 qs_decode_kernel(const unsigned char *__restrict__ pkts, size_t n, size_t stride,
                  const unsigned short *__restrict__ lens, const double *__restrict__ offset,
                  int max_agent, int bots_per_graph, int n_graphs, QsBatch b,
-                 unsigned long long *__restrict__ graph_batch,
+                 unsigned long long *__restrict__ graph_batch, unsigned int *__restrict__ agent_ev,
                  unsigned long long *__restrict__ counters)
 {
     __shared__ unsigned int s_raw[DEC_BLOCK * DEC_MAX_STRIDE / 4 + 2];
+    __shared__ unsigned int s_agent_ev[QS_MAX_AGENT + 1];
     __shared__ unsigned int s_acc, s_hist_small[64][2];
     const size_t base = (size_t)blockIdx.x * DEC_BLOCK;
     const int tid = threadIdx.x;
@@ -27,6 +28,7 @@ qs_decode_kernel(const unsigned char *__restrict__ pkts, size_t n, size_t stride
 
     if (tid == 0) s_acc = 0;
     if (small_g && tid < 64) { s_hist_small[tid][0] = 0; s_hist_small[tid][1] = 0; }
+    for (int t = tid; t <= QS_MAX_AGENT; t += DEC_BLOCK) s_agent_ev[t] = 0;
 
     // stage: the byte range [base*stride, (base+nrec)*stride) widened to dword boundaries
     const size_t byte0 = base * stride;
@@ -98,8 +100,11 @@ qs_decode_kernel(const unsigned char *__restrict__ pkts, size_t n, size_t stride
             if (lmk) atomicAdd(&graph_batch[2 * g + 1], 1ull);
         }
         atomicAdd(&s_acc, 1u);
+        if (lmk) atomicAdd(&s_agent_ev[agent], 1u);
     }
     __syncthreads();
+    for (int t = tid; t <= max_agent; t += DEC_BLOCK)
+        if (s_agent_ev[t]) atomicAdd(&agent_ev[t], s_agent_ev[t]);
     if (small_g && tid < n_graphs) {
         if (s_hist_small[tid][0]) atomicAdd(&graph_batch[2 * tid], (unsigned long long)s_hist_small[tid][0]);
         if (s_hist_small[tid][1]) atomicAdd(&graph_batch[2 * tid + 1], (unsigned long long)s_hist_small[tid][1]);
@@ -115,7 +120,7 @@ __global__ void __launch_bounds__(DEC_BLOCK)
 qs_decode_wide_kernel(const unsigned char *__restrict__ pkts, size_t n, size_t stride,
                       const unsigned short *__restrict__ lens, const double *__restrict__ offset,
                       int max_agent, int bots_per_graph, QsBatch b,
-                      unsigned long long *__restrict__ graph_batch,
+                      unsigned long long *__restrict__ graph_batch, unsigned int *__restrict__ agent_ev,
                       unsigned long long *__restrict__ counters)
 {
     const size_t i = (size_t)blockIdx.x * DEC_BLOCK + threadIdx.x;
@@ -141,7 +146,7 @@ qs_decode_wide_kernel(const unsigned char *__restrict__ pkts, size_t n, size_t s
             b.dist[i] = make_float4(d0, d1, d2, d3); b.enc[i] = enc;
             const int g = (agent - 1) / bots_per_graph;
             atomicAdd(&graph_batch[2 * g], 1ull);
-            if (lmk) atomicAdd(&graph_batch[2 * g + 1], 1ull);
+            if (lmk) { atomicAdd(&graph_batch[2 * g + 1], 1ull); atomicAdd(&agent_ev[agent], 1u); }
             atomicAdd(&counters[QS_CNT_ACCEPTED], 1ull);
         }
     }
@@ -157,10 +162,10 @@ hipError_t qs_launch_decode(qs_ctx *c, const unsigned char *d_pkts, size_t n, si
     if (stride <= DEC_MAX_STRIDE)
         hipLaunchKernelGGL(qs_decode_kernel, dim3(blocks), dim3(DEC_BLOCK), 0, c->stream, d_pkts, n,
                            stride, d_lens, c->d_offset, c->cfg.max_agent, c->bots_per_graph,
-                           c->n_graphs, c->b, c->d_graph_batch, c->d_counters);
+                           c->n_graphs, c->b, c->d_graph_batch, c->sb.agent_ev, c->d_counters);
     else
         hipLaunchKernelGGL(qs_decode_wide_kernel, dim3(blocks), dim3(DEC_BLOCK), 0, c->stream, d_pkts,
                            n, stride, d_lens, c->d_offset, c->cfg.max_agent, c->bots_per_graph, c->b,
-                           c->d_graph_batch, c->d_counters);
+                           c->d_graph_batch, c->sb.agent_ev, c->d_counters);
     return hipGetLastError();
 }

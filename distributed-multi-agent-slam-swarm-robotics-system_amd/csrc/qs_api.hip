@@ -61,6 +61,7 @@ static void graph_free(QsGraphDev &g)
 {
     hipFree(g.lm_x); hipFree(g.lm_y); hipFree(g.lm_idx); hipFree(g.lm_type);
     hipFree(g.cl_lm_idx); hipFree(g.cl_node_idx); hipFree(g.cl_dx); hipFree(g.cl_dy);
+    hipFree(g.dir); hipFree(g.nodes); hipFree(g.nd_next); hipFree(g.misc);
     memset(&g, 0, sizeof g);
 }
 
@@ -81,11 +82,37 @@ static hipError_t grow_array(T **p, long long old_n, long long new_cap, hipStrea
     return hipSuccess;
 }
 
+// node pool: entries are "empty" (idx bytes 0x7f -> a huge node index) and unlinked (next 0)
+static hipError_t grow_pool(qs_ctx *c, QsGraphDev &G, long long old_cap, long long new_cap)
+{
+    QsLmNode *nodes = nullptr; unsigned int *next = nullptr, *misc = nullptr;
+    hipError_t e = hipMalloc((void **)&nodes, (size_t)(new_cap + 1) * sizeof(QsLmNode));
+    if (e == hipSuccess) e = hipMalloc((void **)&next, (size_t)(new_cap + 1) * sizeof(unsigned int));
+    if (e == hipSuccess) e = hipMalloc((void **)&misc, (size_t)new_cap * sizeof(unsigned int));
+    if (e == hipSuccess) e = hipMemsetAsync(nodes, 0x7f, (size_t)(new_cap + 1) * sizeof(QsLmNode), c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(next, 0, (size_t)(new_cap + 1) * sizeof(unsigned int), c->stream);
+    if (e == hipSuccess && G.nodes && old_cap > 0) {
+        e = hipMemcpyAsync(nodes, G.nodes, (size_t)(old_cap + 1) * sizeof(QsLmNode), hipMemcpyDeviceToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(next, G.nd_next, (size_t)(old_cap + 1) * sizeof(unsigned int), hipMemcpyDeviceToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(misc, G.misc, (size_t)old_cap * sizeof(unsigned int), hipMemcpyDeviceToDevice, c->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { hipFree(nodes); hipFree(next); hipFree(misc); return e; }
+    hipFree(G.nodes); hipFree(G.nd_next); hipFree(G.misc);
+    G.nodes = nodes; G.nd_next = next; G.misc = misc;
+    return hipSuccess;
+}
+
 static int graph_reserve(qs_ctx *c, int g, long long need_lms, long long need_cls, long long have_lms,
                          long long have_cls)
 {
     QsGraphDev &G = c->h_graphs[g];
     bool changed = false;
+    if (!G.dir) {
+        HIPCHK(c, hipMalloc((void **)&G.dir, c->dir_entries * sizeof(QsDirEntry)));
+        HIPCHK(c, hipMemsetAsync(G.dir, 0, c->dir_entries * sizeof(QsDirEntry), c->stream));
+        changed = true;
+    }
     if (need_lms > G.cap_lms) {
         long long cap = G.cap_lms ? G.cap_lms : 1024;
         while (cap < need_lms) cap *= 2;
@@ -93,6 +120,7 @@ static int graph_reserve(qs_ctx *c, int g, long long need_lms, long long need_cl
         HIPCHK(c, grow_array(&G.lm_y, have_lms, cap, c->stream));
         HIPCHK(c, grow_array(&G.lm_idx, have_lms, cap, c->stream));
         HIPCHK(c, grow_array(&G.lm_type, have_lms, cap, c->stream));
+        HIPCHK(c, grow_pool(c, G, G.cap_lms, cap));
         G.cap_lms = cap; changed = true;
     }
     if (need_cls > G.cap_cls) {
@@ -105,12 +133,13 @@ static int graph_reserve(qs_ctx *c, int g, long long need_lms, long long need_cl
         G.cap_cls = cap; changed = true;
     }
     if (changed) {
-        // pointers and capacities change; the counters n_* live on the device and are preserved
+        // pointers and capacities change; the counters live on the device and are preserved
         QsGraphDev cur;
         HIPCHK(c, hipMemcpyAsync(&cur, c->d_graphs + g, sizeof cur, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         QsGraphDev upd = G;
         upd.n_nodes = cur.n_nodes; upd.n_lms = cur.n_lms; upd.n_cls = cur.n_cls;
+        upd.n_misc = cur.n_misc; upd.nodes_used = cur.nodes_used ? cur.nodes_used : 1;
         HIPCHK(c, hipMemcpyAsync(c->d_graphs + g, &upd, sizeof upd, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
@@ -133,7 +162,11 @@ static int reset_state(qs_ctx *c)
     std::vector<QsGraphDev> upd(c->h_graphs);
     for (int g = 0; g < c->n_graphs; g++) {
         upd[g].n_nodes = upd[g].n_lms = upd[g].n_cls = 0;
+        upd[g].n_misc = 0; upd[g].nodes_used = 1;
         c->lms_upper[g] = 0; c->cls_upper[g] = 0;
+        HIPCHK(c, hipMemsetAsync(upd[g].dir, 0, c->dir_entries * sizeof(QsDirEntry), c->stream));
+        HIPCHK(c, hipMemsetAsync(upd[g].nodes, 0x7f, (size_t)(upd[g].cap_lms + 1) * sizeof(QsLmNode), c->stream));
+        HIPCHK(c, hipMemsetAsync(upd[g].nd_next, 0, (size_t)(upd[g].cap_lms + 1) * sizeof(unsigned int), c->stream));
     }
     HIPCHK(c, hipMemcpyAsync(c->d_graphs, upd.data(), upd.size() * sizeof(QsGraphDev), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));   // lc / upd are host temporaries
@@ -165,6 +198,16 @@ extern "C" int qs_create(const qs_config *cfg, qs_ctx **out)
     c->r2_threshold = r2_threshold_for(cfg->closure_radius);
     c->cells = (size_t)cfg->size * cfg->size;
     c->geom = QsGeom{cfg->size, cfg->res, cfg->ox, cfg->oy, cfg->min_dist, cfg->max_dist};
+    {   // landmark buckets: edge a hair above the closure radius, so that two points closer than the
+        // radius are never two buckets apart whatever the rounding of (v - b0) / cell
+        const double cell = cfg->closure_radius > 0 ? cfg->closure_radius * (1.0 + 1e-9) : 1.0;
+        const double margin = 2.0 * cell, extent = cfg->size * cfg->res + 2.0 * margin;
+        double nbd = ceil(extent / cell);
+        if (!(nbd >= 1)) nbd = 1;
+        if (nbd > QS_MAX_BUCKETS_1D) nbd = QS_MAX_BUCKETS_1D;
+        c->bg = QsBucketGeom{cfg->ox - margin, cfg->oy - margin, cell, (int)nbd, (int)nbd};
+        c->dir_entries = (size_t)QS_NTYPES * (size_t)c->bg.nbx * (size_t)c->bg.nby;
+    }
     const int nb = cfg->max_agent + 1;
 #define CREATE_CHK(x) do { hipError_t e__ = (x); if (e__ != hipSuccess) { int rc__ = qs_fail(nullptr, QS_E_HIP, #x, e__); qs_destroy(c); return rc__; } } while (0)
     CREATE_CHK(hipSetDevice(c->device));
@@ -205,6 +248,11 @@ static void free_batch(qs_ctx *c)
     hipFree(b.accept); hipFree(b.agent); hipFree(b.lm); hipFree(b.px); hipFree(b.py); hipFree(b.yaw);
     hipFree(b.dist); hipFree(b.enc); hipFree(b.rx); hipFree(b.ry); hipFree(b.hit); hipFree(b.hit_valid);
     memset(&b, 0, sizeof b);
+    QsSlamBatch &sb = c->sb;
+    hipFree(sb.node); hipFree(sb.ev_node); hipFree(sb.ev_agent); hipFree(sb.ev_type); hipFree(sb.ev_px); hipFree(sb.ev_py);
+    hipFree(sb.ev_base); hipFree(sb.acc_total); hipFree(sb.blk_acc); hipFree(sb.blk_ev); hipFree(sb.agent_ev);
+    hipFree(sb.acl_node); hipFree(sb.acl_dx); hipFree(sb.acl_dy); hipFree(sb.acl_cnt); hipFree(sb.drift_start);
+    memset(&sb, 0, sizeof sb);
     c->cap_batch = 0;
 }
 
@@ -319,6 +367,16 @@ static int ensure_batch(qs_ctx *c, size_t n)
     HIPCHK(c, dev_realloc(&b.dist, cap)); HIPCHK(c, dev_realloc(&b.enc, cap));
     HIPCHK(c, dev_realloc(&b.rx, cap)); HIPCHK(c, dev_realloc(&b.ry, cap));
     HIPCHK(c, dev_realloc(&b.hit, 4 * cap)); HIPCHK(c, dev_realloc(&b.hit_valid, 4 * cap));
+    QsSlamBatch &sb = c->sb;
+    const size_t nblk = (size_t)qs_slam_blocks(cap), G = (size_t)c->n_graphs, nb = (size_t)c->cfg.max_agent + 2;
+    HIPCHK(c, dev_realloc(&sb.node, cap)); HIPCHK(c, dev_realloc(&sb.ev_node, cap));
+    HIPCHK(c, dev_realloc(&sb.ev_agent, cap)); HIPCHK(c, dev_realloc(&sb.ev_type, cap));
+    HIPCHK(c, dev_realloc(&sb.ev_px, cap)); HIPCHK(c, dev_realloc(&sb.ev_py, cap));
+    HIPCHK(c, dev_realloc(&sb.ev_base, G + 1)); HIPCHK(c, dev_realloc(&sb.acc_total, G));
+    HIPCHK(c, dev_realloc(&sb.blk_acc, G * nblk)); HIPCHK(c, dev_realloc(&sb.blk_ev, G * nblk));
+    HIPCHK(c, dev_realloc(&sb.agent_ev, nb)); HIPCHK(c, dev_realloc(&sb.acl_cnt, nb));
+    HIPCHK(c, dev_realloc(&sb.acl_node, cap)); HIPCHK(c, dev_realloc(&sb.acl_dx, cap)); HIPCHK(c, dev_realloc(&sb.acl_dy, cap));
+    HIPCHK(c, dev_realloc(&sb.drift_start, 2 * nb));
     c->cap_batch = cap;
     return QS_OK;
 }
@@ -377,6 +435,7 @@ static int ingest_device(qs_ctx *c, const uint8_t *d_pkts, size_t n, size_t stri
     rc = ensure_epoch(c, seq0 - seq0 % sstride, n * sstride);
     if (rc != QS_OK) return rc;
     HIPCHK(c, hipMemsetAsync(c->d_graph_batch, 0, (size_t)c->n_graphs * 2 * sizeof(unsigned long long), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->sb.agent_ev, 0, ((size_t)c->cfg.max_agent + 2) * sizeof(unsigned int), c->stream));
     { StageTimer t(c, QS_STAGE_DECODE); HIPCHK(c, qs_launch_decode(c, d_pkts, n, stride, d_lens)); t.stop(); }
     rc = reserve_graphs_for_batch(c, n);
     if (rc != QS_OK) return rc;

@@ -31,6 +31,17 @@ __host__ __device__ inline double qs_double_from_ord(unsigned long long k)
 #define QS_ORD_MAX_IDENT 0ull                    // identity for atomicMax
 
 // ---- per pose-graph device state (PoseGraphSLAM, dual_bot_mapper.py:261-271) -------------
+// The landmark list is kept twice: as the reference's insertion-ordered log (read-back, and
+// the fallback scan), and as a spatial index: a directory of buckets of edge >= CLOSURE_RADIUS
+// per landmark type, each bucket a chain of 7-entry nodes in insertion order.  A query looks at
+// the 3x3 buckets around it; the first match in list order is the lowest node index among them.
+#define QS_NTYPES 5               // landmark types 1..5 are indexed (LM_CORNER_L..LM_OPEN, :68-74)
+#define QS_NODE_CAP 7
+#define QS_MAX_BUCKETS_1D 2048
+struct alignas(64) QsLmNode { long long idx[8]; double x[8]; double y[8]; };   // idx 0x7f7f.. = empty slot
+struct QsDirEntry { unsigned int head, tail, tail_cnt, pad; };                  // head 0 = empty bucket
+struct QsBucketGeom { double bx0, by0, cell; int nbx, nby; };
+
 struct QsGraphDev {
     long long n_nodes;     // len(self.nodes)
     long long n_lms;       // len(self.landmarks)
@@ -41,6 +52,29 @@ struct QsGraphDev {
     unsigned char *lm_type;
     long long *cl_lm_idx, *cl_node_idx;
     double *cl_dx, *cl_dy;
+    QsDirEntry *dir;       // [QS_NTYPES][nby][nbx]
+    QsLmNode *nodes;       // [cap_lms + 1]; node 0 is the null node
+    unsigned int *nd_next; // [cap_lms + 1]
+    unsigned int *misc;    // [cap_lms] log slots of landmarks the directory does not cover
+    long long n_misc;
+    unsigned int nodes_used, pad0;
+};
+
+// ---- per-batch scratch of the SLAM stage ---------------------------------------------------
+struct QsSlamBatch {
+    long long *node;                       // [n] node index of each record (-1: rejected)
+    long long *ev_node;                    // [n] landmark events, grouped by graph, in node order
+    unsigned char *ev_agent, *ev_type;     //     agent index local to the graph, landmark type
+    double *ev_px, *ev_py;                 //     pose before drift
+    unsigned int *ev_base;                 // [n_graphs + 1] event range of each graph
+    unsigned int *acc_total;               // [n_graphs] accepted records of each graph
+    unsigned int *blk_acc, *blk_ev;        // [n_graphs][n_blocks] per-block counts -> exclusive offsets
+    unsigned int *agent_ev;                // [max_agent + 2] events per bot -> exclusive prefix
+    long long *acl_node;                   // [n] per-bot closure regions: node index of the closure,
+    double *acl_dx, *acl_dy;               //     drift of the bot AFTER it
+    unsigned int *acl_cnt;                 // [max_agent + 1] closures per bot in this batch
+    double *drift_start;                   // [(max_agent + 1) * 2] drift at batch start
+    int n_blocks;
 };
 
 // ---- geometry / constants passed by value to kernels ------------------------------------
@@ -96,6 +130,9 @@ struct qs_ctx {
     unsigned short *d_lens = nullptr;
     double *d_time = nullptr;
     QsBatch b{};
+    QsSlamBatch sb{};
+    QsBucketGeom bg{};
+    size_t dir_entries = 0;      // QS_NTYPES * nbx * nby
     size_t last_n = 0;
     bool last_has_poses = false;
 
@@ -119,8 +156,10 @@ struct qs_ctx {
 // decode.hip
 hipError_t qs_launch_decode(qs_ctx *c, const unsigned char *d_pkts, size_t n, size_t stride,
                             const unsigned short *d_lens);
+#define QS_SLAM_IDX_BLOCK 1024   // records per block of the SLAM index tables
 // slam.hip
 hipError_t qs_launch_slam(qs_ctx *c, size_t n);
+int qs_slam_blocks(size_t n);
 // raycast.hip
 hipError_t qs_launch_raycast_direct(qs_ctx *c, size_t n, uint64_t seq0);
 hipError_t qs_launch_update_rays(qs_ctx *c, const double *rx, const double *ry, const double *hx,
@@ -130,6 +169,7 @@ hipError_t qs_launch_world_to_grid(qs_ctx *c, const double *w, size_t n, int axi
 // raycast_tiled.hip
 hipError_t qs_launch_raycast_tiled(qs_ctx *c, size_t n, uint64_t seq0);
 size_t qs_tiled_workspace_bytes(const qs_ctx *c, size_t n);
+bool qs_tiled_supported(const qs_ctx *c);
 // grid_ops.hip
 hipError_t qs_launch_view_i8(qs_ctx *c, signed char *out_dev);
 hipError_t qs_launch_logodds(qs_ctx *c, float l_occ, float l_free, float lmin, float lmax, float *out_dev);

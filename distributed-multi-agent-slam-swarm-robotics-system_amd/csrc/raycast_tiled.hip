@@ -8,14 +8,19 @@
 // ds_add_u32), and only the touched cells of the tile are merged into the HBM grid, one
 // coalesced 256-byte row per wave-instruction.
 //
-//   pass A  qs_rays_kernel      per ray: projection (fp64 trig), grid end points, zone / hit
-//                                outputs, per-tile counts (wave-aggregated atomics).  Rays longer
-//                                than one tile (fine resolutions) are written directly.
-//   pass B  qs_tile_scan_kernel exclusive scans: records per tile -> record base, chunks per
-//                                tile -> work-item base.
-//   pass C  qs_scatter_kernel   per ray: one 16-byte record per overlapped tile (<= 2x2),
-//                                slots reserved with wave-aggregated atomics.
-//   pass D  qs_raster_kernel    per work item (tile, <= QT_CHUNK records): LDS raster + merge.
+// The sort is a counting sort with NO global atomics (measured: single-lane global atomics on a
+// handful of hot lines cost ~6.5 ns each and dominated the first version, profiles/r01):
+//   pass A  qs_rays_kernel      NWG persistent workgroups, one THREAD per packet: projection of
+//                                the 4 rays (fp64 sincos), grid end points, zone / hit outputs,
+//                                per-tile record counts in an LDS histogram, written as one row
+//                                of the table T[wg][tile].  Rays longer than one tile (fine
+//                                resolutions) are written to the grid directly.
+//   pass B1 qs_table_scan_kernel per tile: exclusive scan of its column of T over the workgroups.
+//   pass B2 qs_tile_scan_kernel  exclusive scans over the tiles: record base and work-item base.
+//   pass C  qs_scatter_kernel    same workgroup decomposition as A: LDS cursors (= table row +
+//                                tile base) hand out record slots; one 16-byte record per
+//                                overlapped tile (<= 2x2 per ray).
+//   pass D  qs_raster_kernel     per work item (tile, <= QT_CHUNK records): LDS raster + merge.
 //
 // HBM traffic per packet (4 rays, ~1.4 tile records per ray): 45 B decoded fields + 64 B ray
 // end points written and read + ~90 B records written and read, independent of how many cells
@@ -27,127 +32,117 @@
 #define QT_TILE_SHIFT 6
 #define QT_CELLS (QT_TILE * QT_TILE)
 #define QT_CHUNK 2048                    // records per raster work item
-#define QT_BLOCK 256
-#define QT_MAX_ITEMS_PAD 8
+#define QT_BLOCK 256                     // raster workgroup
+#define QT_BIN_BLOCK 1024                // pass A / C workgroup
+#define QT_MAX_WG 512                    // persistent workgroups of pass A / C (2 per CU)
+#define QT_MAX_TILES 16384               // LDS histogram limit: 64 KiB (8192^2 cells)
+#define QT_NO_RAY ((int)0x80000000)
 
 struct QtWorkspace {
-    unsigned int *tile_count;    // [n_tiles]   records per tile (pass A)
-    unsigned int *tile_cursor;   // [n_tiles]   scatter cursors (pass C)
+    unsigned int *table;         // [nwg][n_tiles] per-workgroup record counts -> exclusive offsets
+    unsigned int *tile_count;    // [n_tiles]   records per tile
     unsigned int *tile_base;     // [n_tiles+1] exclusive scan of tile_count
     unsigned int *chunk_base;    // [n_tiles+1] exclusive scan of ceil(count / QT_CHUNK)
-    int4 *rays;                  // [4n]        absolute grid end points (x0,y0,x1,y1); x0 = INT_MIN: no record
+    int4 *rays;                  // [4n]        absolute grid end points (x0,y0,x1,y1); x0 = QT_NO_RAY: none
     uint4 *recs;                 // [16n]       tile records
-    int tiles_x, n_tiles;
+    int tiles_x, n_tiles, nwg;
+    size_t pk_per_wg;            // packets per workgroup (multiple of 64)
 };
 
-// ---- wave-aggregated atomicAdd over a small key space -------------------------------------
-// Lanes with equal `key` are served by ONE atomic; returns each lane's slot (base + rank).
-__device__ inline unsigned int qt_wave_agg_add(unsigned int *counters, int key, bool active)
+__device__ inline void qt_tile_range(int x0, int y0, int x1, int y1, int size, int &tx_lo, int &tx_hi,
+                                     int &ty_lo, int &ty_hi)
 {
-    const int lane = threadIdx.x & 63;
-    unsigned int result = 0;
-    unsigned long long remaining = __ballot(active);
-    while (remaining) {
-        const int leader = __ffsll((long long)remaining) - 1;
-        const int k = __shfl(key, leader);
-        const unsigned long long grp = __ballot(active && key == k);
-        if (active && key == k) {
-            const unsigned int rank = __popcll(grp & ((1ull << lane) - 1));
-            unsigned int base = 0;
-            if (rank == 0) base = atomicAdd(&counters[k], (unsigned int)__popcll(grp));
-            base = __shfl(base, leader);
-            result = base + rank;
-        }
-        remaining &= ~grp;
-    }
-    return result;
+    const int xlo = max(min(x0, x1), 0), xhi = min(max(x0, x1), size - 1);
+    const int ylo = max(min(y0, y1), 0), yhi = min(max(y0, y1), size - 1);
+    tx_lo = xlo >> QT_TILE_SHIFT; tx_hi = xhi >> QT_TILE_SHIFT;
+    ty_lo = ylo >> QT_TILE_SHIFT; ty_hi = yhi >> QT_TILE_SHIFT;
 }
 
 // ---- pass A -----------------------------------------------------------------------------------
 template <bool COUNTS>
-__global__ void __launch_bounds__(QT_BLOCK)
+__global__ void __launch_bounds__(QT_BIN_BLOCK)
 qs_rays_kernel(size_t n, QsBatch b, QsGeom geo, QtWorkspace ws, unsigned int *__restrict__ stamps,
                unsigned long long *__restrict__ counts, unsigned long long ord_base, unsigned long long ord_stride,
                unsigned long long *__restrict__ zone, int max_agent, unsigned long long *__restrict__ counters)
 {
+    extern __shared__ unsigned int s_hist[];                       // [n_tiles]
     __shared__ unsigned long long s_zone[QS_MAX_AGENT + 1][4];
     __shared__ unsigned int s_cnt[3];
     const int tid = threadIdx.x;
-    for (int t = tid; t <= max_agent; t += QT_BLOCK) {
+    for (int t = tid; t < ws.n_tiles; t += QT_BIN_BLOCK) s_hist[t] = 0;
+    for (int t = tid; t <= max_agent; t += QT_BIN_BLOCK) {
         s_zone[t][0] = QS_ORD_MIN_IDENT; s_zone[t][1] = QS_ORD_MIN_IDENT;
         s_zone[t][2] = QS_ORD_MAX_IDENT; s_zone[t][3] = QS_ORD_MAX_IDENT;
     }
     if (tid < 3) s_cnt[tid] = 0;
     __syncthreads();
 
-    const size_t r = (size_t)blockIdx.x * QT_BLOCK + tid;
-    const size_t i = r >> 2;
-    const int s = (int)(r & 3);
-    unsigned int my_cells = 0, my_ray = 0, my_hit = 0;
-    bool binned = false;
-    int tx_lo = 0, tx_hi = 0, ty_lo = 0, ty_hi = 0;
-    int4 rec = make_int4((int)0x80000000, 0, 0, 0);
-    if (i < n && b.accept[i]) {
-        const double rx = b.rx[i], ry = b.ry[i], yaw = b.yaw[i];
-        const float4 d4 = b.dist[i];
-        const float df = s == 0 ? d4.x : (s == 1 ? d4.y : (s == 2 ? d4.z : d4.w));
-        const int agent = b.agent[i];
-        QsRay ray = qs_project_ray(rx, ry, yaw, (double)df, s, geo);
-        b.hit[r] = make_double2(ray.ex, ray.ey);
-        b.hit_valid[r] = ray.valid ? 1 : 0;
-        if (s == 0) {   // paths[agent].append  dual_bot_mapper.py:878-879
-            atomicMin(&s_zone[agent][0], qs_ord_from_double(rx)); atomicMin(&s_zone[agent][1], qs_ord_from_double(ry));
-            atomicMax(&s_zone[agent][2], qs_ord_from_double(rx)); atomicMax(&s_zone[agent][3], qs_ord_from_double(ry));
-        }
-        if (ray.valid) {  // point_clouds[agent][name].append  :892
-            atomicMin(&s_zone[agent][0], qs_ord_from_double(ray.ex)); atomicMin(&s_zone[agent][1], qs_ord_from_double(ray.ey));
-            atomicMax(&s_zone[agent][2], qs_ord_from_double(ray.ex)); atomicMax(&s_zone[agent][3], qs_ord_from_double(ray.ey));
-            my_hit = 1;
-        }
-        my_ray = 1;
-        QsLine ln;
-        if (qs_line_setup(ray, rx, ry, geo, ln)) {
-            if (ln.dx < QT_TILE && ln.dy < QT_TILE) {
-                // the ray's cells lie in at most 2 x 2 tiles; clip the tile range to the grid
-                const int xlo = max(min(ln.x0, ln.x1), 0), xhi = min(max(ln.x0, ln.x1), geo.size - 1);
-                const int ylo = max(min(ln.y0, ln.y1), 0), yhi = min(max(ln.y0, ln.y1), geo.size - 1);
-                tx_lo = xlo >> QT_TILE_SHIFT; tx_hi = xhi >> QT_TILE_SHIFT;
-                ty_lo = ylo >> QT_TILE_SHIFT; ty_hi = yhi >> QT_TILE_SHIFT;
-                rec = make_int4(ln.x0, ln.y0, ln.x1, ln.y1);
-                binned = true;
-            } else {
-                // long ray (fine resolution): direct global atomics, as raycast.hip
-                const unsigned int key_free = (unsigned int)((ord_base + ord_stride * i + s + 1) << 1);
-                int x = ln.x0, y = ln.y0, err = ln.dx - ln.dy;
-                for (;;) {
-                    const bool last = (x == ln.x1 && y == ln.y1);
-                    if ((!last || ray.valid) && x >= 0 && x < geo.size && y >= 0 && y < geo.size) {
-                        const size_t c = (size_t)y * geo.size + x;
-                        atomicMax(&stamps[c], key_free | (last ? 1u : 0u));
-                        if (COUNTS) atomicAdd(&counts[c], last ? (1ull << 32) : 1ull);
-                        my_cells++;
+    const size_t p0 = (size_t)blockIdx.x * ws.pk_per_wg;
+    const size_t p1 = (p0 + ws.pk_per_wg < n) ? p0 + ws.pk_per_wg : n;
+    unsigned int my_cells = 0, my_rays = 0, my_hits = 0;
+    for (size_t i = p0 + tid; i < p1; i += QT_BIN_BLOCK) {
+        int4 recs[4];
+        #pragma unroll
+        for (int s = 0; s < 4; s++) recs[s] = make_int4(QT_NO_RAY, 0, 0, 0);
+        if (b.accept[i]) {
+            const double rx = b.rx[i], ry = b.ry[i], yaw = b.yaw[i];
+            const float4 d4 = b.dist[i];
+            const int agent = b.agent[i];
+            const float df[4] = {d4.x, d4.y, d4.z, d4.w};
+            double mnx = rx, mxx = rx, mny = ry, mxy = ry;         // paths[agent].append  :878-879
+            #pragma unroll
+            for (int s = 0; s < 4; s++) {
+                const QsRay ray = qs_project_ray(rx, ry, yaw, (double)df[s], s, geo);
+                b.hit[4 * i + s] = make_double2(ray.ex, ray.ey);
+                b.hit_valid[4 * i + s] = ray.valid ? 1 : 0;
+                if (ray.valid) {                                   // point_clouds[agent][name].append  :892
+                    mnx = ray.ex < mnx ? ray.ex : mnx; mxx = ray.ex > mxx ? ray.ex : mxx;
+                    mny = ray.ey < mny ? ray.ey : mny; mxy = ray.ey > mxy ? ray.ey : mxy;
+                    my_hits++;
+                }
+                my_rays++;
+                QsLine ln;
+                if (!qs_line_setup(ray, rx, ry, geo, ln)) continue;
+                if (ln.dx < QT_TILE && ln.dy < QT_TILE) {
+                    // the ray's cells lie in at most 2 x 2 tiles
+                    int tx_lo, tx_hi, ty_lo, ty_hi;
+                    qt_tile_range(ln.x0, ln.y0, ln.x1, ln.y1, geo.size, tx_lo, tx_hi, ty_lo, ty_hi);
+                    for (int ty = ty_lo; ty <= ty_hi; ty++)
+                        for (int tx = tx_lo; tx <= tx_hi; tx++) atomicAdd(&s_hist[ty * ws.tiles_x + tx], 1u);
+                    recs[s] = make_int4(ln.x0, ln.y0, ln.x1, ln.y1);
+                } else {
+                    // long ray (fine resolution): direct global atomics, as raycast.hip
+                    const unsigned int key_free = (unsigned int)((ord_base + ord_stride * i + s + 1) << 1);
+                    int x = ln.x0, y = ln.y0, err = ln.dx - ln.dy;
+                    for (;;) {
+                        const bool last = (x == ln.x1 && y == ln.y1);
+                        if ((!last || ray.valid) && x >= 0 && x < geo.size && y >= 0 && y < geo.size) {
+                            const size_t c = (size_t)y * geo.size + x;
+                            atomicMax(&stamps[c], key_free | (last ? 1u : 0u));
+                            if (COUNTS) atomicAdd(&counts[c], last ? (1ull << 32) : 1ull);
+                            my_cells++;
+                        }
+                        if (last) break;
+                        const int e2 = 2 * err;
+                        if (e2 > -ln.dy) { err -= ln.dy; x += ln.sx; }
+                        if (e2 < ln.dx) { err += ln.dx; y += ln.sy; }
                     }
-                    if (last) break;
-                    const int e2 = 2 * err;
-                    if (e2 > -ln.dy) { err -= ln.dy; x += ln.sx; }
-                    if (e2 < ln.dx) { err += ln.dx; y += ln.sy; }
                 }
             }
+            // compute_bounding_box over hits U path (:702-706, :930-940): exact min/max, any order
+            atomicMin(&s_zone[agent][0], qs_ord_from_double(mnx)); atomicMin(&s_zone[agent][1], qs_ord_from_double(mny));
+            atomicMax(&s_zone[agent][2], qs_ord_from_double(mxx)); atomicMax(&s_zone[agent][3], qs_ord_from_double(mxy));
         }
+        #pragma unroll
+        for (int s = 0; s < 4; s++) ws.rays[4 * i + s] = recs[s];
     }
-    if (r < 4 * n) ws.rays[r] = rec;
-    // per-tile record counts: up to 2 x 2 tiles per ray, one aggregated atomic per distinct tile
-    #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int tx = tx_lo + (q & 1), ty = ty_lo + (q >> 1);
-        const bool act = binned && tx <= tx_hi && ty <= ty_hi;
-        qt_wave_agg_add(ws.tile_count, ty * ws.tiles_x + tx, act);
-    }
-    if (my_ray) atomicAdd(&s_cnt[0], my_ray);
+    if (my_rays) atomicAdd(&s_cnt[0], my_rays);
     if (my_cells) atomicAdd(&s_cnt[1], my_cells);
-    if (my_hit) atomicAdd(&s_cnt[2], my_hit);
+    if (my_hits) atomicAdd(&s_cnt[2], my_hits);
     __syncthreads();
-    for (int t = tid; t <= max_agent; t += QT_BLOCK) {
+    unsigned int *row = ws.table + (size_t)blockIdx.x * ws.n_tiles;
+    for (int t = tid; t < ws.n_tiles; t += QT_BIN_BLOCK) row[t] = s_hist[t];
+    for (int t = tid; t <= max_agent; t += QT_BIN_BLOCK) {
         if (s_zone[t][0] != QS_ORD_MIN_IDENT) {
             atomicMin(&zone[4 * t + 0], s_zone[t][0]); atomicMin(&zone[4 * t + 1], s_zone[t][1]);
             atomicMax(&zone[4 * t + 2], s_zone[t][2]); atomicMax(&zone[4 * t + 3], s_zone[t][3]);
@@ -160,27 +155,45 @@ qs_rays_kernel(size_t n, QsBatch b, QsGeom geo, QtWorkspace ws, unsigned int *__
     }
 }
 
-// ---- pass B: one workgroup, two exclusive scans over the tiles --------------------------------
+// ---- pass B1: per tile, exclusive scan of its table column over the workgroups -------------------
+__global__ void __launch_bounds__(256)
+qs_table_scan_kernel(QtWorkspace ws)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= ws.n_tiles) return;
+    unsigned int run = 0;
+    int w = 0;
+    for (; w + 8 <= ws.nwg; w += 8) {
+        unsigned int v[8];
+        #pragma unroll
+        for (int q = 0; q < 8; q++) v[q] = ws.table[(size_t)(w + q) * ws.n_tiles + t];
+        #pragma unroll
+        for (int q = 0; q < 8; q++) { ws.table[(size_t)(w + q) * ws.n_tiles + t] = run; run += v[q]; }
+    }
+    for (; w < ws.nwg; w++) { const unsigned int v = ws.table[(size_t)w * ws.n_tiles + t]; ws.table[(size_t)w * ws.n_tiles + t] = run; run += v; }
+    ws.tile_count[t] = run;
+}
+
+// ---- pass B2: one workgroup, two exclusive scans over the tiles --------------------------------
 __global__ void __launch_bounds__(1024)
 qs_tile_scan_kernel(QtWorkspace ws)
 {
     __shared__ unsigned int s_rec[1024], s_chk[1024];
     const int tid = threadIdx.x;
     const int per = (ws.n_tiles + 1023) / 1024;
-    const int lo = tid * per, hi = min(lo + per, ws.n_tiles);
+    const int lo = min(tid * per, ws.n_tiles), hi = min(lo + per, ws.n_tiles);
     unsigned int a = 0, c = 0;
     for (int t = lo; t < hi; t++) { const unsigned int v = ws.tile_count[t]; a += v; c += (v + QT_CHUNK - 1) / QT_CHUNK; }
     s_rec[tid] = a; s_chk[tid] = c;
     __syncthreads();
-    // Hillis-Steele inclusive scan over the 1024 partials
-    for (int off = 1; off < 1024; off <<= 1) {
+    for (int off = 1; off < 1024; off <<= 1) {        // Hillis-Steele inclusive scan of the partials
         unsigned int va = 0, vc = 0;
         if (tid >= off) { va = s_rec[tid - off]; vc = s_chk[tid - off]; }
         __syncthreads();
         s_rec[tid] += va; s_chk[tid] += vc;
         __syncthreads();
     }
-    unsigned int ra = s_rec[tid] - a, rc = s_chk[tid] - c;      // exclusive prefix of this lane's range
+    unsigned int ra = s_rec[tid] - a, rc = s_chk[tid] - c;
     for (int t = lo; t < hi; t++) {
         const unsigned int v = ws.tile_count[t];
         ws.tile_base[t] = ra; ws.chunk_base[t] = rc;
@@ -190,39 +203,35 @@ qs_tile_scan_kernel(QtWorkspace ws)
 }
 
 // ---- pass C: scatter tile records ---------------------------------------------------------------
-__global__ void __launch_bounds__(QT_BLOCK)
-qs_scatter_kernel(size_t n_rays, QsBatch b, QtWorkspace ws, int size, unsigned long long ord_base,
+__global__ void __launch_bounds__(QT_BIN_BLOCK)
+qs_scatter_kernel(size_t n, QsBatch b, QtWorkspace ws, int size, unsigned long long ord_base,
                   unsigned long long ord_stride)
 {
-    const size_t r = (size_t)blockIdx.x * QT_BLOCK + threadIdx.x;
-    int4 ray = make_int4((int)0x80000000, 0, 0, 0);
-    if (r < n_rays) ray = ws.rays[r];
-    const bool binned = ray.x != (int)0x80000000;
-    int tx_lo = 0, tx_hi = -1, ty_lo = 0, ty_hi = -1;
-    unsigned int key_free = 0, flags = 0;
-    if (binned) {
-        const int xlo = max(min(ray.x, ray.z), 0), xhi = min(max(ray.x, ray.z), size - 1);
-        const int ylo = max(min(ray.y, ray.w), 0), yhi = min(max(ray.y, ray.w), size - 1);
-        tx_lo = xlo >> QT_TILE_SHIFT; tx_hi = xhi >> QT_TILE_SHIFT;
-        ty_lo = ylo >> QT_TILE_SHIFT; ty_hi = yhi >> QT_TILE_SHIFT;
-        key_free = (unsigned int)((ord_base + ord_stride * (r >> 2) + (r & 3) + 1) << 1);
-        flags = b.hit_valid[r] ? 1u : 0u;
-    }
-    #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int tx = tx_lo + (q & 1), ty = ty_lo + (q >> 1);
-        const bool act = binned && tx <= tx_hi && ty <= ty_hi;
-        const int tile = ty * ws.tiles_x + tx;
-        const unsigned int slot = qt_wave_agg_add(ws.tile_cursor, tile, act);
-        if (act) {
-            const int ox = tx << QT_TILE_SHIFT, oy = ty << QT_TILE_SHIFT;   // tile origin
-            uint4 rec;
-            rec.x = ((unsigned int)(ray.x - ox) & 0xffffu) | ((unsigned int)(ray.y - oy) << 16);
-            rec.y = ((unsigned int)(ray.z - ox) & 0xffffu) | ((unsigned int)(ray.w - oy) << 16);
-            rec.z = key_free;
-            rec.w = flags;
-            ws.recs[(size_t)ws.tile_base[tile] + slot] = rec;
-        }
+    extern __shared__ unsigned int s_cur[];                        // [n_tiles] next record slot per tile
+    const int tid = threadIdx.x;
+    const unsigned int *row = ws.table + (size_t)blockIdx.x * ws.n_tiles;
+    for (int t = tid; t < ws.n_tiles; t += QT_BIN_BLOCK) s_cur[t] = ws.tile_base[t] + row[t];
+    __syncthreads();
+    const size_t r0 = 4 * (size_t)blockIdx.x * ws.pk_per_wg;
+    const size_t r1 = (r0 + 4 * ws.pk_per_wg < 4 * n) ? r0 + 4 * ws.pk_per_wg : 4 * n;
+    for (size_t r = r0 + tid; r < r1; r += QT_BIN_BLOCK) {
+        const int4 ray = ws.rays[r];
+        if (ray.x == QT_NO_RAY) continue;
+        int tx_lo, tx_hi, ty_lo, ty_hi;
+        qt_tile_range(ray.x, ray.y, ray.z, ray.w, size, tx_lo, tx_hi, ty_lo, ty_hi);
+        const unsigned int key_free = (unsigned int)((ord_base + ord_stride * (r >> 2) + (r & 3) + 1) << 1);
+        const unsigned int flags = b.hit_valid[r] ? 1u : 0u;
+        for (int ty = ty_lo; ty <= ty_hi; ty++)
+            for (int tx = tx_lo; tx <= tx_hi; tx++) {
+                const unsigned int slot = atomicAdd(&s_cur[ty * ws.tiles_x + tx], 1u);
+                const int ox = tx << QT_TILE_SHIFT, oy = ty << QT_TILE_SHIFT;   // tile origin
+                uint4 rec;
+                rec.x = ((unsigned int)(ray.x - ox) & 0xffffu) | ((unsigned int)(ray.y - oy) << 16);
+                rec.y = ((unsigned int)(ray.z - ox) & 0xffffu) | ((unsigned int)(ray.w - oy) << 16);
+                rec.z = key_free;
+                rec.w = flags;
+                ws.recs[slot] = rec;
+            }
     }
 }
 
@@ -306,17 +315,25 @@ qs_raster_kernel(QtWorkspace ws, int size, unsigned int *__restrict__ stamps,
 // ---- host side ------------------------------------------------------------------------------------
 static inline size_t qt_align(size_t v) { return (v + 255) & ~(size_t)255; }
 
-size_t qs_tiled_workspace_bytes(const qs_ctx *c, size_t n)
+static inline int qt_n_tiles(const qs_ctx *c)
 {
     const int tiles_x = (c->cfg.size + QT_TILE - 1) / QT_TILE;
-    const size_t n_tiles = (size_t)tiles_x * tiles_x;
-    return 4 * qt_align((n_tiles + 1) * sizeof(unsigned int)) + qt_align(4 * n * sizeof(int4)) +
-           qt_align(16 * n * sizeof(uint4));
+    return tiles_x * tiles_x;
+}
+
+bool qs_tiled_supported(const qs_ctx *c) { return qt_n_tiles(c) <= QT_MAX_TILES; }
+
+size_t qs_tiled_workspace_bytes(const qs_ctx *c, size_t n)
+{
+    const size_t n_tiles = (size_t)qt_n_tiles(c);
+    return qt_align((size_t)QT_MAX_WG * n_tiles * sizeof(unsigned int)) + 3 * qt_align((n_tiles + 1) * sizeof(unsigned int)) +
+           qt_align(4 * n * sizeof(int4)) + qt_align(16 * n * sizeof(uint4));
 }
 
 hipError_t qs_launch_raycast_tiled(qs_ctx *c, size_t n, uint64_t seq0)
 {
     if (n == 0) return hipSuccess;
+    if (!qs_tiled_supported(c)) return qs_launch_raycast_direct(c, n, seq0);
     const size_t need = qs_tiled_workspace_bytes(c, c->cap_batch);
     if (need > c->bin_ws_bytes) {
         hipError_t e = hipStreamSynchronize(c->stream);
@@ -329,33 +346,37 @@ hipError_t qs_launch_raycast_tiled(qs_ctx *c, size_t n, uint64_t seq0)
     QtWorkspace ws;
     ws.tiles_x = (c->cfg.size + QT_TILE - 1) / QT_TILE;
     ws.n_tiles = ws.tiles_x * ws.tiles_x;
+    // packets per workgroup: a multiple of 64, at least 256, and at most QT_MAX_WG workgroups
+    size_t per = (n + QT_MAX_WG - 1) / QT_MAX_WG;
+    per = per < 256 ? 256 : ((per + 63) & ~(size_t)63);
+    ws.pk_per_wg = per;
+    ws.nwg = (int)((n + per - 1) / per);
     const size_t tbytes = qt_align(((size_t)ws.n_tiles + 1) * sizeof(unsigned int));
     char *p = (char *)c->d_bin_ws;
+    ws.table = (unsigned int *)p; p += qt_align((size_t)QT_MAX_WG * ws.n_tiles * sizeof(unsigned int));
     ws.tile_count = (unsigned int *)p; p += tbytes;
-    ws.tile_cursor = (unsigned int *)p; p += tbytes;
     ws.tile_base = (unsigned int *)p; p += tbytes;
     ws.chunk_base = (unsigned int *)p; p += tbytes;
     ws.rays = (int4 *)p; p += qt_align(4 * c->cap_batch * sizeof(int4));
     ws.recs = (uint4 *)p;
-    hipError_t e = hipMemsetAsync(ws.tile_count, 0, 2 * tbytes, c->stream);   // counts + cursors
-    if (e != hipSuccess) return e;
 
     const unsigned long long ord_base = 4ull * (seq0 - c->epoch_base);
     const unsigned long long ord_stride = 4ull * (unsigned long long)(c->cfg.seq_stride > 0 ? c->cfg.seq_stride : 1);
     const size_t n_rays = 4 * n;
-    const unsigned int ray_blocks = (unsigned int)((n_rays + QT_BLOCK - 1) / QT_BLOCK);
+    const size_t lds = (size_t)ws.n_tiles * sizeof(unsigned int);
     // upper bound on raster work items: every record in a full chunk, plus one partial chunk per tile
-    size_t max_items = (4 * n_rays) / QT_CHUNK + (size_t)ws.n_tiles + QT_MAX_ITEMS_PAD;
+    size_t max_items = (4 * n_rays) / QT_CHUNK + (size_t)ws.n_tiles + 8;
     if (max_items > 4 * n_rays) max_items = 4 * n_rays;
     if (c->cfg.enable_counts) {
-        hipLaunchKernelGGL(qs_rays_kernel<true>, dim3(ray_blocks), dim3(QT_BLOCK), 0, c->stream, n, c->b, c->geom, ws,
+        hipLaunchKernelGGL(qs_rays_kernel<true>, dim3(ws.nwg), dim3(QT_BIN_BLOCK), lds, c->stream, n, c->b, c->geom, ws,
                            c->d_stamps, c->d_counts, ord_base, ord_stride, c->d_zone, c->cfg.max_agent, c->d_counters);
     } else {
-        hipLaunchKernelGGL(qs_rays_kernel<false>, dim3(ray_blocks), dim3(QT_BLOCK), 0, c->stream, n, c->b, c->geom, ws,
+        hipLaunchKernelGGL(qs_rays_kernel<false>, dim3(ws.nwg), dim3(QT_BIN_BLOCK), lds, c->stream, n, c->b, c->geom, ws,
                            c->d_stamps, c->d_counts, ord_base, ord_stride, c->d_zone, c->cfg.max_agent, c->d_counters);
     }
+    hipLaunchKernelGGL(qs_table_scan_kernel, dim3((ws.n_tiles + 255) / 256), dim3(256), 0, c->stream, ws);
     hipLaunchKernelGGL(qs_tile_scan_kernel, dim3(1), dim3(1024), 0, c->stream, ws);
-    hipLaunchKernelGGL(qs_scatter_kernel, dim3(ray_blocks), dim3(QT_BLOCK), 0, c->stream, n_rays, c->b, ws,
+    hipLaunchKernelGGL(qs_scatter_kernel, dim3(ws.nwg), dim3(QT_BIN_BLOCK), lds, c->stream, n, c->b, ws,
                        c->cfg.size, ord_base, ord_stride);
     if (c->cfg.enable_counts)
         hipLaunchKernelGGL(qs_raster_kernel<true>, dim3((unsigned int)max_items), dim3(QT_BLOCK), 0, c->stream, ws,

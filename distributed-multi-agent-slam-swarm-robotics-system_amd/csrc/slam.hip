@@ -2,187 +2,465 @@
 // Semantics: PoseGraphSLAM.add_pose / _check_closure (server_nodes/dual_bot_mapper.py:273-326)
 // and the drift application around it (:855-857, :908-914).
 //
-// The reference is a sequential recurrence: a closure at node i changes the pose of every
-// later packet of that agent.  Two facts make it batchable without changing any result:
+// The reference is a sequential recurrence: a closure at node i changes the pose of every later
+// packet of that agent, and with it the landmarks that agent stores and the matches it finds.
+// Only the closures are sequential, so the stage is split:
+//
+//   index  (parallel)  node index of every accepted record inside its pose graph (a stable
+//                      partition by graph) and the compacted list of landmark events per graph;
+//   chain  (one wave per graph) walks ONLY the landmark events, in node order, in windows;
+//   pose   (parallel)  every record's pose = raw + drift of its bot at that node, looked up in
+//                      the bot's closure list of the batch.
+//
+// Two facts keep the chain exact while letting a window be handled at once:
 //   (1) a landmark stored at node j can only be matched by a node i >= j + MIN_POSES_BETWEEN
 //       (:300), and after a closure an agent cannot close again for MIN_POSES_BETWEEN nodes
-//       (:304); hence inside a window of W <= MIN_POSES_BETWEEN consecutive nodes no event can
-//       see a landmark of the same window and each agent closes at most once;
-//   (2) landmarks are appended in node order (:288), so "idx - lm_idx >= MIN" selects a
-//       prefix of the list and the first match in list order is the lowest matching slot.
-// One workgroup per pose graph walks its packets in arrival order, window by window; inside a
-// window every eligible landmark event scans the landmark list with the whole workgroup
-// (lowest matching slot = first match in insertion order), then one lane commits the closures
-// in node order and re-poses the closing agent's later packets of the window.
+//       (:304); so inside a window spanning < MIN_POSES_BETWEEN nodes no event can see a
+//       landmark of the same window, every event is evaluated with the drift at window start,
+//       and each agent closes at most once: at its first eligible event that has a match;
+//   (2) landmarks are appended in node order (:288), so "idx - lm_idx >= MIN" selects a prefix
+//       and the first match in list order is the LOWEST node index among the matches.
+// The match search uses the spatial index of QsGraphDev: buckets of edge >= CLOSURE_RADIUS per
+// landmark type, entries in insertion order; the 3x3 buckets around a query contain every
+// landmark within the radius, and the minimum node index over their first matches is the
+// reference's first match.  Landmarks the directory does not cover (type > 5, or outside the
+// bucket grid) live in a side list that every query also scans.
 #include "qs_internal.h"
 
-#define SLAM_BLOCK 256
-#define SLAM_WAVES (SLAM_BLOCK / QS_WAVE)
 #define LL_MAX 0x7fffffffffffffffll
+#define IDX_BLOCK QS_SLAM_IDX_BLOCK
+#define IDX_WAVES (IDX_BLOCK / QS_WAVE)
 
-__global__ void __launch_bounds__(SLAM_BLOCK)
-qs_slam_kernel(QsGraphDev *__restrict__ graphs, int bots_per_graph, int max_agent, size_t n,
-               QsBatch b, double *__restrict__ drift, long long *__restrict__ last_closure,
-               int win, int min_between, double r2thr, double corr,
-               unsigned long long *__restrict__ counters)
+int qs_slam_blocks(size_t n) { return (int)((n + IDX_BLOCK - 1) / IDX_BLOCK); }
+
+// ---- index pass 1: per block, accepted records and landmark events of every graph ------------
+__global__ void __launch_bounds__(IDX_BLOCK)
+qs_slam_count_kernel(size_t n, QsBatch b, QsSlamBatch sb, int bots_per_graph, int n_graphs)
 {
-    const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ unsigned int s_acc[QS_MAX_AGENT + 1], s_ev[QS_MAX_AGENT + 1];
+    const int tid = threadIdx.x;
+    for (int t = tid; t < n_graphs; t += IDX_BLOCK) { s_acc[t] = 0; s_ev[t] = 0; }
+    __syncthreads();
+    const size_t i = (size_t)blockIdx.x * IDX_BLOCK + tid;
+    if (i < n && b.accept[i]) {
+        const int g = ((int)b.agent[i] - 1) / bots_per_graph;
+        atomicAdd(&s_acc[g], 1u);
+        if (b.lm[i]) atomicAdd(&s_ev[g], 1u);
+    }
+    __syncthreads();
+    for (int t = tid; t < n_graphs; t += IDX_BLOCK) {
+        sb.blk_acc[(size_t)t * sb.n_blocks + blockIdx.x] = s_acc[t];
+        sb.blk_ev[(size_t)t * sb.n_blocks + blockIdx.x] = s_ev[t];
+    }
+}
+
+// ---- index pass 2: per graph, exclusive scan of its block counts -------------------------------
+__global__ void __launch_bounds__(256)
+qs_slam_blockscan_kernel(QsSlamBatch sb)
+{
+    __shared__ unsigned int s_a[256], s_e[256];
+    const int g = blockIdx.x, tid = threadIdx.x;
+    unsigned int *acc = sb.blk_acc + (size_t)g * sb.n_blocks, *ev = sb.blk_ev + (size_t)g * sb.n_blocks;
+    const int per = (sb.n_blocks + 255) / 256;
+    const int lo = min(tid * per, sb.n_blocks), hi = min(lo + per, sb.n_blocks);
+    unsigned int a = 0, e = 0;
+    for (int k = lo; k < hi; k++) { a += acc[k]; e += ev[k]; }
+    s_a[tid] = a; s_e[tid] = e;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned int ra = 0, re = 0;
+        for (int t = 0; t < 256; t++) { const unsigned int va = s_a[t], ve = s_e[t]; s_a[t] = ra; s_e[t] = re; ra += va; re += ve; }
+        sb.acc_total[g] = ra;
+        sb.ev_base[g + 1] = re;          // totals for now; made a prefix by the next kernel
+    }
+    __syncthreads();
+    unsigned int ra = s_a[tid], re = s_e[tid];
+    for (int k = lo; k < hi; k++) { const unsigned int va = acc[k], ve = ev[k]; acc[k] = ra; ev[k] = re; ra += va; re += ve; }
+}
+
+// ---- index pass 2b: prefix over graphs (event ranges) and over bots (closure regions) ----------
+__global__ void qs_slam_prefix_kernel(QsSlamBatch sb, int n_graphs, int max_agent, const double *__restrict__ drift)
+{
+    if (threadIdx.x == 0) {
+        unsigned int run = 0;
+        sb.ev_base[0] = 0;
+        for (int g = 0; g < n_graphs; g++) { run += sb.ev_base[g + 1]; sb.ev_base[g + 1] = run; }
+    }
+    if (threadIdx.x == 64) {
+        unsigned int run = 0;
+        for (int a = 0; a <= max_agent + 1; a++) { const unsigned int v = a <= max_agent ? sb.agent_ev[a] : 0; sb.agent_ev[a] = run; run += v; }
+    }
+    for (int t = threadIdx.x; t <= max_agent; t += blockDim.x) {
+        sb.acl_cnt[t] = 0;
+        sb.drift_start[2 * t] = drift[2 * t];
+        sb.drift_start[2 * t + 1] = drift[2 * t + 1];
+    }
+}
+
+// ---- index pass 3: node index per record, event records per graph (stable in arrival order) ----
+__global__ void __launch_bounds__(IDX_BLOCK)
+qs_slam_index_kernel(size_t n, QsBatch b, QsSlamBatch sb, const QsGraphDev *__restrict__ graphs,
+                     int bots_per_graph, int n_graphs)
+{
+    extern __shared__ unsigned int s_w[];          // [IDX_WAVES][n_graphs][2] per-wave counts
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int t = tid; t < IDX_WAVES * n_graphs * 2; t += IDX_BLOCK) s_w[t] = 0;
+    __syncthreads();
+    const size_t i = (size_t)blockIdx.x * IDX_BLOCK + tid;
+    const bool acc = i < n && b.accept[i];
+    int g = -1, agent = 0, lmk = 0;
+    if (acc) { agent = b.agent[i]; g = (agent - 1) / bots_per_graph; lmk = b.lm[i]; }
+    // ranks inside the wave, per graph, in lane (= arrival) order
+    unsigned int rank = 0, rank_ev = 0;
+    unsigned long long remaining = __ballot(acc);
+    while (remaining) {
+        const int leader = __ffsll((long long)remaining) - 1;
+        const int k = __shfl(g, leader);
+        const unsigned long long grp = __ballot(acc && g == k);
+        const unsigned long long egrp = __ballot(acc && g == k && lmk != 0);
+        if (acc && g == k) {
+            rank = __popcll(grp & ((1ull << lane) - 1));
+            rank_ev = __popcll(egrp & ((1ull << lane) - 1));
+            if (lane == leader) {
+                s_w[(wave * n_graphs + k) * 2] = __popcll(grp);
+                s_w[(wave * n_graphs + k) * 2 + 1] = __popcll(egrp);
+            }
+        }
+        remaining &= ~grp;
+    }
+    __syncthreads();
+    if (acc) {
+        unsigned int off = 0, off_ev = 0;
+        for (int w = 0; w < wave; w++) { off += s_w[(w * n_graphs + g) * 2]; off_ev += s_w[(w * n_graphs + g) * 2 + 1]; }
+        const long long node = graphs[g].n_nodes + sb.blk_acc[(size_t)g * sb.n_blocks + blockIdx.x] + off + rank;   // len(self.nodes)  :275
+        sb.node[i] = node;
+        if (lmk) {
+            const size_t e = (size_t)sb.ev_base[g] + sb.blk_ev[(size_t)g * sb.n_blocks + blockIdx.x] + off_ev + rank_ev;
+            sb.ev_node[e] = node;
+            sb.ev_agent[e] = (unsigned char)(agent - 1 - g * bots_per_graph);
+            sb.ev_type[e] = (unsigned char)lmk;
+            sb.ev_px[e] = b.px[i];
+            sb.ev_py[e] = b.py[i];
+        }
+    } else if (i < n) {
+        sb.node[i] = -1;
+    }
+}
+
+// ---- the chain: one wave per pose graph -----------------------------------------------------------
+__device__ inline int nth_set_bit(unsigned long long m, int nth)
+{
+    for (int q = 0; q < nth; q++) m &= m - 1;
+    return m ? __ffsll((long long)m) - 1 : -1;
+}
+
+__device__ inline long long bucket_coord(double v, double b0, double cell)
+{
+    const double f = floor((v - b0) / cell);
+    return (fabs(f) < 1.0e9) ? (long long)f : -1000000000ll;
+}
+
+__global__ void __launch_bounds__(QS_WAVE)
+qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGeom bg, int bots_per_graph,
+                     int max_agent, int win, int min_between, double r2thr, double corr,
+                     double *__restrict__ drift, long long *__restrict__ last_closure,
+                     unsigned long long *__restrict__ counters)
+{
+    const int g = blockIdx.x, lane = threadIdx.x;
     QsGraphDev G = graphs[g];
     const int bot0 = g * bots_per_graph + 1;
     const int nb = min(bots_per_graph, max_agent - bot0 + 1);
 
     __shared__ double s_drift[QS_MAX_AGENT + 1][2];
     __shared__ long long s_last[QS_MAX_AGENT + 1];
-    __shared__ int s_list[SLAM_BLOCK];
-    __shared__ int s_wave_cnt[SLAM_WAVES];
-    __shared__ long long s_red[SLAM_WAVES];
-    __shared__ int w_pkt[QS_WIN_MAX], w_agent[QS_WIN_MAX], w_type[QS_WIN_MAX], w_elig[QS_WIN_MAX];
-    __shared__ long long w_idx[QS_WIN_MAX], w_match[QS_WIN_MAX];
-    __shared__ double w_x[QS_WIN_MAX], w_y[QS_WIN_MAX];
-    __shared__ long long s_ncls;
-    __shared__ int s_add;
+    __shared__ unsigned int s_acnt[QS_MAX_AGENT + 1];
+    __shared__ long long s_bidx[QS_WAVE];
+    __shared__ double s_bx[QS_WAVE], s_by[QS_WAVE];
+    __shared__ long long s_ridx[32];
+    __shared__ double s_rx[32], s_ry[32];
 
-    for (int t = tid; t < nb; t += SLAM_BLOCK) {
+    for (int t = lane; t < nb; t += QS_WAVE) {
         s_drift[t][0] = drift[2 * (bot0 + t)];
         s_drift[t][1] = drift[2 * (bot0 + t) + 1];
         s_last[t] = last_closure[bot0 + t];
+        s_acnt[t] = 0;
     }
-    if (tid == 0) s_ncls = G.n_cls;
-    long long n_nodes = G.n_nodes, n_lms = G.n_lms;
     __syncthreads();
 
-    for (size_t base = 0; base < n; base += SLAM_BLOCK) {
-        // this graph's accepted packets of the chunk, compacted in arrival order
-        const size_t i = base + tid;
-        bool mine = false;
-        if (i < n && b.accept[i]) mine = ((int)b.agent[i] - 1) / bots_per_graph == g;
-        const unsigned long long m = __ballot(mine);
-        if (lane == 0) s_wave_cnt[wave] = __popcll(m);
-        __syncthreads();
-        int off = 0, cnt = 0;
-        #pragma unroll
-        for (int w = 0; w < SLAM_WAVES; w++) { if (w < wave) off += s_wave_cnt[w]; cnt += s_wave_cnt[w]; }
-        if (mine) s_list[off + __popcll(m & ((1ull << lane) - 1))] = tid;
+    const unsigned int e0 = sb.ev_base[g], e1 = sb.ev_base[g + 1];
+    long long n_lms = G.n_lms, n_cls = G.n_cls, n_misc = G.n_misc;
+    unsigned int pool = G.nodes_used;
+    const long long dir_slab = (long long)bg.nbx * bg.nby;
+
+    for (unsigned int e = e0; e < e1;) {
+        // ---- window: the next events whose node index is < first + win ---------------------------
+        const bool have = lane < 32 && e + lane < e1;
+        long long idx = have ? sb.ev_node[e + lane] : LL_MAX;
+        const long long first = __shfl(idx, 0);
+        const bool inw = have && idx < first + win;
+        const int k = __popcll(__ballot(inw));                  // a contiguous prefix of the lanes
+        int a = 0, type = 0;
+        double px = 0, py = 0;
+        if (inw) { a = sb.ev_agent[e + lane]; type = sb.ev_type[e + lane]; px = sb.ev_px[e + lane]; py = sb.ev_py[e + lane]; }
+        double x = px + s_drift[a][0];                          // rx += cdx  :856
+        double y = py + s_drift[a][1];                          // ry += cdy  :857
+        const bool elig = inw && (idx - s_last[a] >= min_between);                     // :304
+        const unsigned long long emask = __ballot(elig);
+        if (lane < 32) s_ridx[lane] = LL_MAX;
         __syncthreads();
 
-        for (int w0 = 0; w0 < cnt; w0 += win) {
-            const int wn = min(win, cnt - w0);
-            if (tid < wn) {
-                const size_t p = base + s_list[w0 + tid];
-                const int a = (int)b.agent[p] - bot0, t = b.lm[p];
-                const long long idx = n_nodes + w0 + tid;             // len(self.nodes)  :275
-                w_pkt[tid] = s_list[w0 + tid];
-                w_agent[tid] = a; w_type[tid] = t; w_idx[tid] = idx;
-                w_x[tid] = b.px[p] + s_drift[a][0];                   // rx += cdx  :856
-                w_y[tid] = b.py[p] + s_drift[a][1];                   // ry += cdy  :857
-                w_elig[tid] = (t != 0) && (idx - s_last[a] >= min_between);   // :283, :304
-                w_match[tid] = -1;
+        // ---- queries: 9 lanes (the 3x3 buckets) per eligible event, 7 events per round -----------
+        const int n_elig = __popcll(emask);
+        for (int round = 0; round * 7 < n_elig; round++) {
+            const int gq = lane / 9, nbk = lane % 9;
+            const int src = lane < 63 ? nth_set_bit(emask, round * 7 + gq) : -1;
+            const bool active = src >= 0;
+            const int sl = active ? src : 0;
+            const double qx = __shfl(x, sl), qy = __shfl(y, sl);
+            const int qtype = __shfl(type, sl);
+            const long long limit = __shfl(idx, sl) - min_between;                     // :300
+            unsigned int node = 0;
+            if (active && qtype >= 1 && qtype <= QS_NTYPES) {
+                const long long cx = bucket_coord(qx, bg.bx0, bg.cell) + (nbk % 3) - 1;
+                const long long cy = bucket_coord(qy, bg.by0, bg.cell) + (nbk / 3) - 1;
+                if (cx >= 0 && cx < bg.nbx && cy >= 0 && cy < bg.nby)
+                    node = G.dir[(qtype - 1) * dir_slab + cy * bg.nbx + cx].head;
+            }
+            long long best = LL_MAX;
+            double bx = 0, by = 0;
+            while (__ballot(node != 0)) {
+                bool stop = false, found = false;
+                unsigned int nxt = 0;
+                long long last_idx = LL_MAX;
+                if (node) {
+                    const QsLmNode *nd = G.nodes + node;
+                    long long id[QS_NODE_CAP]; double nx[QS_NODE_CAP], ny[QS_NODE_CAP];
+                    #pragma unroll
+                    for (int s = 0; s < QS_NODE_CAP; s++) { id[s] = nd->idx[s]; nx[s] = nd->x[s]; ny[s] = nd->y[s]; }
+                    nxt = G.nd_next[node];
+                    last_idx = id[QS_NODE_CAP - 1];
+                    #pragma unroll
+                    for (int s = 0; s < QS_NODE_CAP; s++) {
+                        if (!found && !stop) {
+                            if (id[s] > limit) stop = true;     // later entries are later nodes still
+                            else {
+                                const double dx = qx - nx[s], dy = qy - ny[s];
+                                if (dx * dx + dy * dy < r2thr) { found = true; best = id[s]; bx = nx[s]; by = ny[s]; }   // :308-309
+                            }
+                        }
+                    }
+                }
+                s_bidx[lane] = best;
+                __syncthreads();
+                long long gbest = LL_MAX;
+                if (lane < 63) {
+                    #pragma unroll
+                    for (int q = 0; q < 9; q++) { const long long v = s_bidx[gq * 9 + q]; gbest = v < gbest ? v : gbest; }
+                }
+                __syncthreads();
+                if (node) node = (found || stop || nxt == 0 || last_idx >= gbest) ? 0u : nxt;
+            }
+            // deliver the group's first match (lowest node index) to the event's lane
+            s_bidx[lane] = best; s_bx[lane] = bx; s_by[lane] = by;
+            __syncthreads();
+            if (active && nbk == 0) {
+                long long m = LL_MAX; double mx = 0, my = 0;
+                #pragma unroll
+                for (int q = 0; q < 9; q++) {
+                    const long long v = s_bidx[gq * 9 + q];
+                    if (v < m) { m = v; mx = s_bx[gq * 9 + q]; my = s_by[gq * 9 + q]; }
+                }
+                s_ridx[src] = m; s_rx[src] = mx; s_ry[src] = my;
             }
             __syncthreads();
-
-            for (int j = 0; j < wn; j++) {
-                if (!w_elig[j]) continue;                              // uniform
-                const long long limit = w_idx[j] - min_between;       // :300  idx - lm_idx >= MIN
-                const int type = w_type[j];
-                const double qx = w_x[j], qy = w_y[j];
-                long long found = -1;
-                for (long long c0 = 0; c0 < n_lms; c0 += SLAM_BLOCK) {
-                    const long long k = c0 + tid;
-                    bool cand = false;
-                    if (k < n_lms && G.lm_idx[k] <= limit && G.lm_type[k] == type) {   // :296, :300
-                        const double dx = qx - G.lm_x[k], dy = qy - G.lm_y[k];
-                        cand = (dx * dx + dy * dy) < r2thr;            // sqrt(..) < RADIUS  :308-309
+        }
+        // ---- landmarks outside the directory: linear scan in insertion order (rare) ---------------
+        if (n_misc > 0) {
+            unsigned long long rem = emask;
+            while (rem) {
+                const int src = __ffsll((long long)rem) - 1;
+                rem &= rem - 1;
+                const double qx = __shfl(x, src), qy = __shfl(y, src);
+                const int qtype = __shfl(type, src);
+                const long long limit = __shfl(idx, src) - min_between;
+                for (long long c0 = 0; c0 < n_misc; c0 += QS_WAVE) {
+                    const long long k2 = c0 + lane;
+                    bool cand = false, beyond = false;
+                    long long li = LL_MAX; double lx = 0, ly = 0;
+                    if (k2 < n_misc) {
+                        const unsigned int slot = G.misc[k2];
+                        li = G.lm_idx[slot];
+                        beyond = li > limit;
+                        if (!beyond && G.lm_type[slot] == qtype) {
+                            lx = G.lm_x[slot]; ly = G.lm_y[slot];
+                            const double dx = qx - lx, dy = qy - ly;
+                            cand = dx * dx + dy * dy < r2thr;
+                        }
                     }
                     const unsigned long long cm = __ballot(cand);
-                    if (lane == 0) s_red[wave] = cm ? (c0 + wave * QS_WAVE + __ffsll((long long)cm) - 1) : LL_MAX;
-                    const long long lastk = (c0 + SLAM_BLOCK - 1 < n_lms - 1) ? c0 + SLAM_BLOCK - 1 : n_lms - 1;
-                    const bool beyond = G.lm_idx[lastk] > limit;       // list is ascending in idx
-                    __syncthreads();
-                    long long first = s_red[0];
-                    #pragma unroll
-                    for (int w = 1; w < SLAM_WAVES; w++) first = s_red[w] < first ? s_red[w] : first;
-                    __syncthreads();
-                    if (first != LL_MAX) { found = first; break; }
-                    if (beyond) break;
-                }
-                if (tid == 0) w_match[j] = found;
-            }
-            __syncthreads();
-
-            if (tid == 0) {
-                // commit closures in node order  (:309-324, :910-914)
-                long long ncls = s_ncls;
-                for (int j = 0; j < wn; j++) {
-                    if (!w_elig[j] || w_match[j] < 0) continue;
-                    const int a = w_agent[j];
-                    if (w_idx[j] - s_last[a] < min_between) continue;  // an earlier closure of this window
-                    const long long mslot = w_match[j];
-                    const double ex = G.lm_x[mslot] - w_x[j], ey = G.lm_y[mslot] - w_y[j];   // :311-312
-                    const double cdx = ex * corr, cdy = ey * corr;                           // :314-315
-                    if (ncls < G.cap_cls) {
-                        G.cl_lm_idx[ncls] = G.lm_idx[mslot]; G.cl_node_idx[ncls] = w_idx[j];  // :317
-                        G.cl_dx[ncls] = cdx; G.cl_dy[ncls] = cdy;
+                    if (cm) {
+                        const int w = __ffsll((long long)cm) - 1;
+                        const long long widx = __shfl(li, w);
+                        const double wx = __shfl(lx, w), wy = __shfl(ly, w);
+                        if (lane == 0 && widx < s_ridx[src]) { s_ridx[src] = widx; s_rx[src] = wx; s_ry[src] = wy; }
+                        break;
                     }
-                    ncls++;
-                    s_last[a] = w_idx[j];                                                     // :318
-                    s_drift[a][0] = s_drift[a][0] + cdx;                                      // :911-914
-                    s_drift[a][1] = s_drift[a][1] + cdy;
-                    for (int j2 = j + 1; j2 < wn; j2++)
-                        if (w_agent[j2] == a) {
-                            const size_t p2 = base + w_pkt[j2];
-                            w_x[j2] = b.px[p2] + s_drift[a][0];
-                            w_y[j2] = b.py[p2] + s_drift[a][1];
-                        }
+                    if (__ballot(beyond)) break;
                 }
-                s_ncls = ncls;
+                __syncthreads();
             }
-            __syncthreads();
-
-            if (wave == 0) {
-                const bool act = tid < wn;
-                const bool ev = act && w_type[tid] != 0;
-                const unsigned long long em = __ballot(ev);
-                if (act) {
-                    const size_t p = base + w_pkt[tid];
-                    b.rx[p] = w_x[tid];
-                    b.ry[p] = w_y[tid];
-                }
-                if (ev) {                                              // self.landmarks.append  :288
-                    const long long slot = n_lms + __popcll(em & ((1ull << lane) - 1));
-                    if (slot < G.cap_lms) {
-                        G.lm_x[slot] = w_x[tid]; G.lm_y[slot] = w_y[tid];
-                        G.lm_idx[slot] = w_idx[tid]; G.lm_type[slot] = (unsigned char)w_type[tid];
-                    }
-                }
-                if (lane == 0) s_add = __popcll(em);
-            }
-            __syncthreads();
-            n_lms += s_add;
         }
-        n_nodes += cnt;
+        const long long m_idx = lane < 32 ? s_ridx[lane] : LL_MAX;
+        const double m_x = lane < 32 ? s_rx[lane] : 0, m_y = lane < 32 ? s_ry[lane] : 0;
+        const bool matched = elig && m_idx != LL_MAX;
+
+        // ---- resolve: per agent, its first eligible event with a match closes the loop ------------
+        bool closes = matched;
+        {
+            unsigned long long rem = __ballot(matched);
+            while (rem) {
+                const int c = __ffsll((long long)rem) - 1;
+                const int ac = __shfl(a, c);
+                const unsigned long long same = __ballot(matched && a == ac);
+                if (matched && a == ac && lane != c) closes = false;
+                rem &= ~same;
+            }
+        }
+        const unsigned long long cmask = __ballot(closes);
+        if (closes) {
+            const double ex = m_x - x, ey = m_y - y;                                   // :311-312
+            const double cdx = ex * corr, cdy = ey * corr;                             // :314-315
+            const double ndx = s_drift[a][0] + cdx, ndy = s_drift[a][1] + cdy;         // :911-914
+            const long long slot = n_cls + __popcll(cmask & ((1ull << lane) - 1));
+            if (slot < G.cap_cls) {
+                G.cl_lm_idx[slot] = m_idx; G.cl_node_idx[slot] = idx;                  // :317
+                G.cl_dx[slot] = cdx; G.cl_dy[slot] = cdy;
+            }
+            const unsigned int pos = sb.agent_ev[bot0 + a] + s_acnt[a];
+            sb.acl_node[pos] = idx; sb.acl_dx[pos] = ndx; sb.acl_dy[pos] = ndy;
+            s_acnt[a] = s_acnt[a] + 1;
+            s_drift[a][0] = ndx; s_drift[a][1] = ndy;
+            s_last[a] = idx;                                                           // :318
+        }
+        n_cls += __popcll(cmask);
+        __syncthreads();
+        // later events of a closing agent in this window are posed (and stored) with the new drift
+        if (inw && !closes && s_last[a] >= first && s_last[a] < idx) {
+            x = px + s_drift[a][0];
+            y = py + s_drift[a][1];
+        }
+
+        // ---- self.landmarks.append((x, y, landmark_type, idx))  :288 -----------------------------
+        const long long log_slot = n_lms + lane;
+        if (inw && log_slot < G.cap_lms) {
+            G.lm_x[log_slot] = x; G.lm_y[log_slot] = y; G.lm_idx[log_slot] = idx; G.lm_type[log_slot] = (unsigned char)type;
+        }
+        // spatial index insert: events of one bucket are appended in lane (= node) order
+        long long key = -1;
+        if (inw && type >= 1 && type <= QS_NTYPES) {
+            const long long cx = bucket_coord(x, bg.bx0, bg.cell), cy = bucket_coord(y, bg.by0, bg.cell);
+            if (cx >= 0 && cx < bg.nbx && cy >= 0 && cy < bg.nby) key = (type - 1) * dir_slab + cy * bg.nbx + cx;
+        }
+        const bool inb = key >= 0;
+        const bool is_misc = inw && !inb;
+        {
+            const unsigned long long mm = __ballot(is_misc);
+            if (is_misc) G.misc[n_misc + __popcll(mm & ((1ull << lane) - 1))] = (unsigned int)log_slot;
+            n_misc += __popcll(mm);
+        }
+        QsDirEntry de = {0, 0, 0, 0};
+        if (inb) de = G.dir[key];
+        unsigned long long rem = __ballot(inb);
+        while (rem) {
+            const int ld = __ffsll((long long)rem) - 1;
+            const long long kk = __shfl(key, ld);
+            const unsigned long long grp = __ballot(inb && key == kk);
+            const int gsize = __popcll(grp);
+            const unsigned int head = __shfl(de.head, ld), tail = __shfl(de.tail, ld);
+            const unsigned int tc = head ? __shfl(de.tail_cnt, ld) : QS_NODE_CAP;   // no tail node yet: "full"
+            const unsigned int total = tc + gsize;
+            const unsigned int nn = total > QS_NODE_CAP ? (total - QS_NODE_CAP + QS_NODE_CAP - 1) / QS_NODE_CAP : 0;
+            const unsigned int base = pool;
+            if (inb && key == kk) {
+                const unsigned int p = tc + __popcll(grp & ((1ull << lane) - 1));
+                const unsigned int nd = p < QS_NODE_CAP ? tail : base + (p - QS_NODE_CAP) / QS_NODE_CAP;
+                const unsigned int sl = p < QS_NODE_CAP ? p : (p - QS_NODE_CAP) % QS_NODE_CAP;
+                QsLmNode *np = G.nodes + nd;
+                np->idx[sl] = idx; np->x[sl] = x; np->y[sl] = y;
+                if (lane == ld) {
+                    QsDirEntry upd;
+                    upd.head = head; upd.tail = tail; upd.tail_cnt = total; upd.pad = 0;
+                    if (nn) {
+                        for (unsigned int q = 0; q + 1 < nn; q++) G.nd_next[base + q] = base + q + 1;
+                        if (head) G.nd_next[tail] = base; else upd.head = base;
+                        upd.tail = base + nn - 1;
+                        upd.tail_cnt = total - QS_NODE_CAP * nn;
+                    }
+                    G.dir[kk] = upd;
+                }
+            }
+            pool += nn;
+            rem &= ~grp;
+        }
+        n_lms += k;
+        e += k;
+        // stores of this window (landmarks, directory) are ordered before the next window's loads
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __syncthreads();
     }
 
-    for (int t = tid; t < nb; t += SLAM_BLOCK) {
+    for (int t = lane; t < nb; t += QS_WAVE) {
         drift[2 * (bot0 + t)] = s_drift[t][0];
         drift[2 * (bot0 + t) + 1] = s_drift[t][1];
         last_closure[bot0 + t] = s_last[t];
+        sb.acl_cnt[bot0 + t] = s_acnt[t];
     }
-    if (tid == 0) {
-        atomicAdd(&counters[QS_CNT_CLOSURES], (unsigned long long)(s_ncls - G.n_cls));
+    if (lane == 0) {
+        atomicAdd(&counters[QS_CNT_CLOSURES], (unsigned long long)(n_cls - G.n_cls));
         atomicAdd(&counters[QS_CNT_LANDMARKS], (unsigned long long)(n_lms - G.n_lms));
-        graphs[g].n_nodes = n_nodes;
+        graphs[g].n_nodes = G.n_nodes + sb.acc_total[g];
         graphs[g].n_lms = n_lms;
-        graphs[g].n_cls = s_ncls;
+        graphs[g].n_cls = n_cls;
+        graphs[g].n_misc = n_misc;
+        graphs[g].nodes_used = pool;
     }
+}
+
+// ---- pose: rx, ry of every accepted record (dual_bot_mapper.py:855-857) ---------------------------
+// drift of the record's bot = drift after that bot's last closure at a node index < the record's
+// (a closure at node j is applied to packets after j, :910-914), else the drift at batch start.
+__global__ void __launch_bounds__(256)
+qs_slam_pose_kernel(size_t n, QsBatch b, QsSlamBatch sb)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || !b.accept[i]) return;
+    const int agent = b.agent[i];
+    const long long node = sb.node[i];
+    const unsigned int base = sb.agent_ev[agent];
+    int lo = 0, hi = (int)sb.acl_cnt[agent];       // first closure with acl_node >= node
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (sb.acl_node[base + mid] < node) lo = mid + 1; else hi = mid; }
+    double dx, dy;
+    if (lo == 0) { dx = sb.drift_start[2 * agent]; dy = sb.drift_start[2 * agent + 1]; }
+    else { dx = sb.acl_dx[base + lo - 1]; dy = sb.acl_dy[base + lo - 1]; }
+    b.rx[i] = b.px[i] + dx;
+    b.ry[i] = b.py[i] + dy;
 }
 
 hipError_t qs_launch_slam(qs_ctx *c, size_t n)
 {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(qs_slam_kernel, dim3(c->n_graphs), dim3(SLAM_BLOCK), 0, c->stream, c->d_graphs,
-                       c->bots_per_graph, c->cfg.max_agent, n, c->b, c->d_drift, c->d_last_closure,
-                       c->win, c->cfg.min_poses_between, c->r2_threshold, c->cfg.closure_correction,
-                       c->d_counters);
+    QsSlamBatch sb = c->sb;
+    sb.n_blocks = qs_slam_blocks(n);
+    const int G = c->n_graphs;
+    hipLaunchKernelGGL(qs_slam_count_kernel, dim3(sb.n_blocks), dim3(IDX_BLOCK), 0, c->stream, n, c->b, sb,
+                       c->bots_per_graph, G);
+    hipLaunchKernelGGL(qs_slam_blockscan_kernel, dim3(G), dim3(256), 0, c->stream, sb);
+    hipLaunchKernelGGL(qs_slam_prefix_kernel, dim3(1), dim3(256), 0, c->stream, sb, G, c->cfg.max_agent, c->d_drift);
+    hipLaunchKernelGGL(qs_slam_index_kernel, dim3(sb.n_blocks), dim3(IDX_BLOCK), (size_t)IDX_WAVES * G * 2 * sizeof(unsigned int),
+                       c->stream, n, c->b, sb, c->d_graphs, c->bots_per_graph, G);
+    hipLaunchKernelGGL(qs_slam_chain_kernel, dim3(G), dim3(QS_WAVE), 0, c->stream, c->d_graphs, sb, c->bg,
+                       c->bots_per_graph, c->cfg.max_agent, c->win, c->cfg.min_poses_between, c->r2_threshold,
+                       c->cfg.closure_correction, c->d_drift, c->d_last_closure, c->d_counters);
+    hipLaunchKernelGGL(qs_slam_pose_kernel, dim3((unsigned int)((n + 255) / 256)), dim3(256), 0, c->stream, n, c->b, sb);
     return hipGetLastError();
 }

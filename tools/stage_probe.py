@@ -16,14 +16,13 @@ def main():
     dev = torch.device("cuda", 0)
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     cases = []
-    for B in (1 << 16, 1 << 20):
-        for mode in (1, 2):
-            for counts in (True, False):
-                cases.append(dict(B=B, mode=mode, counts=counts, ekf=False, bots=2))
+    cases.append(dict(B=1 << 20, mode=1, counts=True, ekf=False, bots=2))
+    cases.append(dict(B=1 << 20, mode=2, counts=True, ekf=False, bots=2))
+    cases.append(dict(B=1 << 20, mode=2, counts=False, ekf=False, bots=2))
+    cases.append(dict(B=1 << 16, mode=2, counts=True, ekf=False, bots=2))
     cases.append(dict(B=1 << 18, mode=2, counts=True, ekf=True, bots=2))
     cases.append(dict(B=1 << 20, mode=2, counts=True, ekf=False, bots=64))
     cases.append(dict(B=1 << 20, mode=2, counts=True, ekf=True, bots=64))
-    cases.append(dict(B=1 << 20, mode=1, counts=True, ekf=False, bots=64))
     cases.append(dict(B=1 << 20, mode=2, counts=True, ekf=False, bots=64, bpg=2))
     cases.append(dict(B=1 << 20, mode=2, counts=True, ekf=False, bots=0))   # adversarial random stream
     cases.append(dict(B=1 << 20, mode=1, counts=True, ekf=False, bots=0))
