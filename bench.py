@@ -46,15 +46,17 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(stream, grid, sample):
+def cpu_baseline(stream, grid, sample, ekf, times):
     """The oracle (C restatement of the reference path, 1 thread) on a bounded prefix of the
     same stream.  Reported, never the thing shipped."""
     from oracle import oracle as orc
     n = min(sample, len(stream))
     half = grid * 0.05 / 2
     m = orc.OracleMapper(grid, 0.05, -half, -half, 0.0, max_agent=2)
+    if ekf:
+        m.enable_ekf(0.0107)
     t0 = time.perf_counter()
-    m.feed_stream(stream[:n])
+    m.feed_stream(stream[:n], None, times[:n])
     dt = time.perf_counter() - t0
     return {"value": n / dt, "unit": "packets/s", "cores": 1, "kind": "port",
             "sample": f"first {n} packets of the same stream, oracle/oracle.c (gcc -O2), {dt:.2f} s, "
@@ -156,7 +158,7 @@ def main():
                          "avg_launch_ms": ray_avg_s * 1e3},
         }
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(stream, G, args.cpu_sample)
+            out["cpu_baseline"] = cpu_baseline(stream, G, args.cpu_sample, bool(args.ekf), np.arange(B) * 0.25)
         print(json.dumps(out))
     m.close()
     if world > 1:

@@ -12,7 +12,9 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libquasar_slam.so")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "quasar_slam.h")
 
-QS_CNT_NAMES = ("datagrams", "accepted", "rays", "cells", "hits", "closures", "landmarks", "rebases")
+QS_CNT_NAMES = ("datagrams", "accepted", "rays", "cells", "hits", "closures", "landmarks", "rebases",
+                "slam_windows", "slam_rounds", "slam_node_iters", "slam_misc_iters", "slam_cycles",
+                "slam_realtime_100mhz")
 QS_STAGE_NAMES = ("decode", "slam", "raycast", "ekf", "bin")
 UINT64_MAX = (1 << 64) - 1
 

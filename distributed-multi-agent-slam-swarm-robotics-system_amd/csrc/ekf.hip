@@ -14,6 +14,31 @@
 #define EKF_STRIDE 44   // x[6], P[36], last_time, initialized
 #define EKF_PI 3.14159265358979323846
 
+// sin/cos for the filter's heading (|theta| stays near [-pi, pi]): Cody-Waite reduction by pi/2 in
+// three pieces and the classic degree-13/14 minimax kernels; ~35 instructions instead of two
+// general-range library calls on the critical path of a strictly serial recurrence.  (The raycast
+// keeps the library's sin/cos: there the value decides a cell index.)
+__device__ inline void ekf_sincos(double x, double *sn, double *cs)
+{
+    if (!(fabs(x) < 1.0e5)) { *sn = sin(x); *cs = cos(x); return; }
+    const double n = rint(x * 6.36619772367581382433e-01);
+    double r = x - n * 1.57079632673412561417e+00;
+    r = r - n * 6.07710050630396597660e-11;
+    r = r - n * 2.02226624879595063154e-21;
+    const double z = r * r;
+    const double ps = __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, 1.58969099521155010221e-10,
+                      -2.50507602534068634195e-08), 2.75573137070700676789e-06), -1.98412698298579493134e-04),
+                      8.33333333332248946124e-03);
+    const double s = __builtin_fma(z * r, __builtin_fma(z, ps, -1.66666666666666324348e-01), r);
+    const double pc = __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z,
+                      -1.13596475577881948265e-11, 2.08757232129817482790e-09), -2.75573143513906633035e-07),
+                      2.48015872894767294178e-05), -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+    const double c = 1.0 - (0.5 * z - z * (z * pc));
+    const int q = (int)n & 3;
+    *sn = (q == 0) ? s : (q == 1) ? c : (q == 2) ? -s : -c;
+    *cs = (q == 0) ? c : (q == 1) ? -s : (q == 2) ? -c : s;
+}
+
 struct EkfState { double x[6]; double P[36]; double last_t; double init; };
 
 __device__ inline void ekf_load(const double *f, EkfState &s)
@@ -54,7 +79,8 @@ __device__ inline void ekf_predict(EkfState &s, double omega_measured, double t)
     double theta_new = theta + omega_c * dt;
     if (theta_new > EKF_PI) theta_new -= 2 * EKF_PI;
     else if (theta_new < -EKF_PI) theta_new += 2 * EKF_PI;
-    const double ct = cos(theta), st = sin(theta);
+    double ct, st;
+    ekf_sincos(theta, &st, &ct);
     const double x_new = s.x[0] + v * ct * dt;
     const double y_new = s.x[1] + v * st * dt;
     s.x[0] = x_new; s.x[1] = y_new; s.x[2] = theta_new; s.x[4] = omega_c;
@@ -127,9 +153,23 @@ __device__ inline void ekf_update(EkfState &s, double z_v, double z_omega)   // 
 // Per accepted packet of a bot, in arrival order: first packet initialises the filter at the
 // packet pose; later packets derive omega_m = wrap(yaw - yaw_prev)/dt and
 // v_enc = (enc - enc_prev) * metres_per_tick / dt, then predict(omega_m, t); update(v_enc, omega_m).
-// One wave per bot: the wave scans the batch 64 records at a time (coalesced), ballots the
-// records of its bot and steps through them in order; the filter state is wave-uniform.
+//
+// The filter is a strict recurrence per bot, so one wave serves one bot and the 6x6 covariance
+// is spread over 36 lanes: lane l = 6r + c holds P[r][c] and a copy of x[r].  J P J^T needs the
+// column-mates (rows 2,3,5) and then the row-mates (columns 2,3,5) of each element, (I-KH)P the
+// row-mates (columns 3,4) and column-mates (rows 3,4): ten 64-bit shuffles per step instead of
+// ~450 dependent fp64 instructions on one lane.  Every element is evaluated with exactly the
+// operand order of ekf_predict / ekf_update above, so both forms agree bit for bit.
 #define EKF_BLOCK 256
+
+__device__ inline double ekf_rl(double v, int src_lane)      // wave-uniform read of one lane
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, src_lane);
+    hi = __builtin_amdgcn_readlane(hi, src_lane);
+    return __hiloint2double(hi, lo);
+}
+
 __global__ void __launch_bounds__(EKF_BLOCK)
 qs_ekf_ingest_kernel(size_t n, QsBatch b, const double *__restrict__ recv_time, double t_nominal0,
                      double *__restrict__ ekf, double *__restrict__ prev, int max_agent, double metres_per_tick)
@@ -137,49 +177,114 @@ qs_ekf_ingest_kernel(size_t n, QsBatch b, const double *__restrict__ recv_time, 
     const int lane = threadIdx.x & 63;
     const int bot = blockIdx.x * (EKF_BLOCK / QS_WAVE) + (threadIdx.x >> 6) + 1;
     if (bot > max_agent) return;
-    EkfState s;
-    ekf_load(ekf + (size_t)bot * EKF_STRIDE, s);
+    const int l = lane < 36 ? lane : 0;
+    const int r = l / 6, c = l % 6;
+    double *f = ekf + (size_t)bot * EKF_STRIDE;
+    double P = f[6 + l], xr = f[r];
+    double last_t = f[42], init = f[43];
     double pt = prev[4 * bot], pyaw = prev[4 * bot + 1], penc = prev[4 * bot + 2], seen = prev[4 * bot + 3];
+    const double Qd[6] = {0.01, 0.01, 0.01, 0.1, 0.1, 0.001};                          // ekf.cpp:11
+    const double qdiag = (r == c) ? Qd[r] : 0.0;
+    const double R0 = 0.05, R1 = 0.05;                                                  // ekf.cpp:12
+
     for (size_t base = 0; base < n; base += QS_WAVE) {
         const size_t i = base + lane;
         const bool mine = i < n && b.accept[i] && b.agent[i] == bot;
         unsigned long long m = __ballot(mine);
+        if (!m) continue;
+        // the chunk's fields, one coalesced load per array; each step then reads its record by lane
+        double t_l = 0, px_l = 0, py_l = 0, yaw_l = 0, enc_l = 0;
+        if (mine) {
+            t_l = recv_time ? recv_time[i] : t_nominal0 + (double)i;
+            px_l = b.px[i]; py_l = b.py[i]; yaw_l = b.yaw[i]; enc_l = (double)b.enc[i];
+        }
         while (m) {
             const int j = __ffsll((long long)m) - 1;
             m &= m - 1;
-            const size_t p = base + j;
-            const double t = recv_time ? recv_time[p] : t_nominal0 + (double)p;
-            const double x = b.px[p], y = b.py[p], yaw = b.yaw[p], enc = (double)b.enc[p];
-            if (seen == 0.0) {
-                const double x0[6] = {x, y, yaw, 0, 0, 0};
-                ekf_init(s, t, x0);
+            const double t = ekf_rl(t_l, j), px = ekf_rl(px_l, j), py = ekf_rl(py_l, j), yaw = ekf_rl(yaw_l, j),
+                         enc = ekf_rl(enc_l, j);
+            if (seen == 0.0) {                                    // EKF::EKF + init  ekf.cpp:5-19
+                const double x0[6] = {px, py, yaw, 0, 0, 0};
+                xr = x0[r]; P = (r == c) ? 1.0 : 0.0; last_t = t; init = 1.0;
             } else {
-                const double dt = t - pt;
-                if (dt > 0) {
+                const double dtp = t - pt;
+                if (dtp > 0) {
                     double dyaw = yaw - pyaw;
                     if (dyaw > EKF_PI) dyaw -= 2 * EKF_PI;
                     else if (dyaw < -EKF_PI) dyaw += 2 * EKF_PI;
-                    const double omega_m = dyaw / dt;
-                    const double v_enc = (enc - penc) * metres_per_tick / dt;
-                    ekf_predict(s, omega_m, t);
-                    ekf_update(s, v_enc, omega_m);
+                    const double omega_m = dyaw / dtp;
+                    const double v_enc = (enc - penc) * metres_per_tick / dtp;
+                    // ---- predict  ekf.cpp:26-68 ----
+                    const double dt = t - last_t;
+                    if (init != 0.0 && dt > 0) {
+                        last_t = t;
+                        const double theta = ekf_rl(xr, 12), v = ekf_rl(xr, 18), bias = ekf_rl(xr, 30);
+                        const double omega_c = omega_m - bias;
+                        double theta_new = theta + omega_c * dt;
+                        if (theta_new > EKF_PI) theta_new -= 2 * EKF_PI;
+                        else if (theta_new < -EKF_PI) theta_new += 2 * EKF_PI;
+                        double ct, st;
+                        ekf_sincos(theta, &st, &ct);
+                        if (r == 0) xr = xr + v * ct * dt;
+                        else if (r == 1) xr = xr + v * st * dt;
+                        else if (r == 2) xr = theta_new;
+                        else if (r == 4) xr = omega_c;
+                        const double j02 = -v * st * dt, j03 = ct * dt, j12 = v * ct * dt, j13 = st * dt, j25 = -dt;
+                        const double p2 = __shfl(P, 12 + c), p3 = __shfl(P, 18 + c), p5 = __shfl(P, 30 + c);
+                        double JP;
+                        if (r == 0) JP = (P + j02 * p2) + j03 * p3;
+                        else if (r == 1) JP = (P + j12 * p2) + j13 * p3;
+                        else if (r == 2) JP = P + j25 * p5;
+                        else if (r == 4) JP = -1.0 * p5;
+                        else JP = P;
+                        const double r2 = __shfl(JP, 6 * r + 2), r3 = __shfl(JP, 6 * r + 3), r5 = __shfl(JP, 6 * r + 5);
+                        double M;
+                        if (c == 0) M = (JP + r2 * j02) + r3 * j03;
+                        else if (c == 1) M = (JP + r2 * j12) + r3 * j13;
+                        else if (c == 2) M = JP + r5 * j25;
+                        else if (c == 4) M = r5 * -1.0;
+                        else M = JP;
+                        P = M + qdiag;
+                    }
+                    // ---- update  ekf.cpp:70-92 ----
+                    if (init != 0.0) {
+                        const double y0 = v_enc - ekf_rl(xr, 18), y1 = omega_m - ekf_rl(xr, 24);
+                        const double s00 = ekf_rl(P, 21) + R0, s01 = ekf_rl(P, 22);
+                        const double s10 = ekf_rl(P, 27), s11 = ekf_rl(P, 28) + R1;
+                        const double det = s00 * s11 - s01 * s10;
+                        const double i00 = s11 / det, i01 = -s01 / det, i10 = -s10 / det, i11 = s00 / det;
+                        const double pr3 = __shfl(P, 6 * r + 3), pr4 = __shfl(P, 6 * r + 4);
+                        const double K0 = pr3 * i00 + pr4 * i10, K1 = pr3 * i01 + pr4 * i11;
+                        xr = xr + (K0 * y0 + K1 * y1);
+                        const double p3c = __shfl(P, 18 + c), p4c = __shfl(P, 24 + c);
+                        double Pn;
+                        if (r < 3) Pn = (P + (-K0) * p3c) + (-K1) * p4c;
+                        else if (r == 3) Pn = (1.0 - K0) * p3c + (-K1) * p4c;
+                        else if (r == 4) Pn = (-K0) * p3c + (1.0 - K1) * p4c;
+                        else Pn = ((-K0) * p3c + (-K1) * p4c) + P;
+                        P = Pn;
+                    }
                 }
             }
             pt = t; pyaw = yaw; penc = enc; seen = 1.0;
         }
     }
+    if (lane < 36) {
+        f[6 + lane] = P;
+        if (c == 0) f[r] = xr;
+    }
     if (lane == 0) {
-        ekf_store(ekf + (size_t)bot * EKF_STRIDE, s);
+        f[42] = last_t; f[43] = init;
         prev[4 * bot] = pt; prev[4 * bot + 1] = pyaw; prev[4 * bot + 2] = penc; prev[4 * bot + 3] = seen;
     }
 }
 
-hipError_t qs_launch_ekf_ingest(qs_ctx *c, size_t n, const double *d_time)
+hipError_t qs_launch_ekf_ingest(qs_ctx *c, size_t n, const double *d_time, hipStream_t st)
 {
     if (n == 0) return hipSuccess;
     const int waves = EKF_BLOCK / QS_WAVE;
     hipLaunchKernelGGL(qs_ekf_ingest_kernel, dim3((c->cfg.max_agent + waves - 1) / waves), dim3(EKF_BLOCK), 0,
-                       c->stream, n, c->b, d_time, (double)c->next_seq, c->d_ekf, c->d_ekf_prev, c->cfg.max_agent,
+                       st, n, c->b, d_time, (double)c->next_seq, c->d_ekf, c->d_ekf_prev, c->cfg.max_agent,
                        c->cfg.ekf_metres_per_tick);
     return hipGetLastError();
 }

@@ -269,6 +269,9 @@ extern "C" int qs_destroy(qs_ctx *c)
     hipFree(c->d_time); hipFree(c->d_bin_ws);
     for (auto &p : c->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (auto e : c->ev_pool) hipEventDestroy(e);
+    if (c->ekf_stream) { hipStreamSynchronize(c->ekf_stream); hipStreamDestroy(c->ekf_stream); }
+    if (c->ev_decoded) hipEventDestroy(c->ev_decoded);
+    if (c->ev_ekf_done) hipEventDestroy(c->ev_ekf_done);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
     delete c;
     return QS_OK;
@@ -325,10 +328,10 @@ static hipEvent_t ev_get(qs_ctx *c)
     return e;
 }
 struct StageTimer {
-    qs_ctx *c; int stage; hipEvent_t a = nullptr, b = nullptr;
-    StageTimer(qs_ctx *c_, int s) : c(c_), stage(s)
-    { if (c->timing) { a = ev_get(c); b = ev_get(c); hipEventRecord(a, c->stream); } }
-    void stop() { if (c->timing && a) { hipEventRecord(b, c->stream); c->pending.push_back({stage, a, b}); a = nullptr; } }
+    qs_ctx *c; int stage; hipStream_t st; hipEvent_t a = nullptr, b = nullptr;
+    StageTimer(qs_ctx *c_, int s, hipStream_t st_ = nullptr) : c(c_), stage(s), st(st_ ? st_ : c_->stream)
+    { if (c->timing) { a = ev_get(c); b = ev_get(c); hipEventRecord(a, st); } }
+    void stop() { if (c->timing && a) { hipEventRecord(b, st); c->pending.push_back({stage, a, b}); a = nullptr; } }
 };
 
 extern "C" int qs_timing_enable(qs_ctx *c, int32_t enable)
@@ -439,6 +442,18 @@ static int ingest_device(qs_ctx *c, const uint8_t *d_pkts, size_t n, size_t stri
     { StageTimer t(c, QS_STAGE_DECODE); HIPCHK(c, qs_launch_decode(c, d_pkts, n, stride, d_lens)); t.stop(); }
     rc = reserve_graphs_for_batch(c, n);
     if (rc != QS_OK) return rc;
+    if (c->cfg.enable_ekf) {
+        // fork: the filter only needs the decoded fields, never the map (and the map never the filter)
+        if (!c->ekf_stream) {
+            HIPCHK(c, hipStreamCreateWithFlags(&c->ekf_stream, hipStreamNonBlocking));
+            HIPCHK(c, hipEventCreateWithFlags(&c->ev_decoded, hipEventDisableTiming));
+            HIPCHK(c, hipEventCreateWithFlags(&c->ev_ekf_done, hipEventDisableTiming));
+        }
+        HIPCHK(c, hipEventRecord(c->ev_decoded, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(c->ekf_stream, c->ev_decoded, 0));
+        { StageTimer t(c, QS_STAGE_EKF, c->ekf_stream); HIPCHK(c, qs_launch_ekf_ingest(c, n, d_time, c->ekf_stream)); t.stop(); }
+        HIPCHK(c, hipEventRecord(c->ev_ekf_done, c->ekf_stream));
+    }
     { StageTimer t(c, QS_STAGE_SLAM); HIPCHK(c, qs_launch_slam(c, n)); t.stop(); }
     {
         StageTimer t(c, QS_STAGE_RAYCAST);
@@ -446,7 +461,7 @@ static int ingest_device(qs_ctx *c, const uint8_t *d_pkts, size_t n, size_t stri
         else HIPCHK(c, qs_launch_raycast_tiled(c, n, seq0));      // 0 (auto) and 2
         t.stop();
     }
-    if (c->cfg.enable_ekf) { StageTimer t(c, QS_STAGE_EKF); HIPCHK(c, qs_launch_ekf_ingest(c, n, d_time)); t.stop(); }
+    if (c->cfg.enable_ekf) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_ekf_done, 0));   // join
     c->next_seq = seq0 + n * sstride;
     return QS_OK;
 }

@@ -103,6 +103,8 @@ struct qs_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    hipStream_t ekf_stream = nullptr;            // the EKF is independent of the map: own stream,
+    hipEvent_t ev_decoded = nullptr, ev_ekf_done = nullptr;   // forked after decode, joined at the end
     std::string err;
     size_t cells = 0;
     int n_graphs = 0, bots_per_graph = 0, win = 30;
@@ -185,6 +187,6 @@ hipError_t qs_launch_rasterise(qs_ctx *c, const double *d_xy, size_t n, double r
                                double miny, int h, int w, signed char *d_grid);
 hipError_t qs_launch_bbox(qs_ctx *c, const double *d_xy, size_t n, unsigned long long *d_box4);
 // ekf.hip
-hipError_t qs_launch_ekf_ingest(qs_ctx *c, size_t n, const double *d_time);
+hipError_t qs_launch_ekf_ingest(qs_ctx *c, size_t n, const double *d_time, hipStream_t st);
 hipError_t qs_launch_ekf_step(qs_ctx *c, const int *d_bots, const double *d_omega, const double *d_t,
                               const double *d_zv, const double *d_zo, size_t n, int do_update);

@@ -147,11 +147,22 @@ qs_slam_index_kernel(size_t n, QsBatch b, QsSlamBatch sb, const QsGraphDev *__re
     }
 }
 
-// ---- the chain: one wave per pose graph -----------------------------------------------------------
-__device__ inline int nth_set_bit(unsigned long long m, int nth)
+// ---- the chain: one workgroup (CH_WAVES waves) per pose graph ------------------------------------
+// Per window: wave 0 loads the window's events and prepares them SIMD-across-events (pose with the
+// drift at window start, eligibility, bucket key and 3x3 neighbour mask); the eligible events are
+// then queried one per wave, in parallel; wave 0 commits closures in node order and appends the
+// window's landmarks to the log and the spatial index.  A lone wave issues roughly one instruction
+// per 4-8 cycles, so everything that can be done once per window instead of once per query is.
+#define CH_WAVES 16
+#define CH_THREADS (CH_WAVES * QS_WAVE)
+
+// barrier that orders LDS traffic only (the two intra-window hand-offs go through LDS; a full
+// __syncthreads would also wait for every outstanding global store to be acknowledged)
+__device__ inline void lds_barrier()
 {
-    for (int q = 0; q < nth; q++) m &= m - 1;
-    return m ? __ffsll((long long)m) - 1 : -1;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
 __device__ inline long long bucket_coord(double v, double b0, double cell)
@@ -160,13 +171,37 @@ __device__ inline long long bucket_coord(double v, double b0, double cell)
     return (fabs(f) < 1.0e9) ? (long long)f : -1000000000ll;
 }
 
-__global__ void __launch_bounds__(QS_WAVE)
+__device__ inline long long rl64(long long v, int src_lane)      // wave-uniform read of one lane
+{
+    int lo = (int)(v & 0xffffffffll), hi = (int)(v >> 32);
+    lo = __builtin_amdgcn_readlane(lo, src_lane);
+    hi = __builtin_amdgcn_readlane(hi, src_lane);
+    return ((long long)hi << 32) | (unsigned int)lo;
+}
+
+// bucket key of the 3x3 centre and the mask of neighbours that exist in the directory
+__device__ inline void bucket_prepare(double x, double y, int type, const QsBucketGeom &bg, long long dir_slab,
+                                      long long &kb, unsigned int &nbmask)
+{
+    kb = -1; nbmask = 0;
+    if (type < 1 || type > QS_NTYPES) return;
+    const long long cx = bucket_coord(x, bg.bx0, bg.cell), cy = bucket_coord(y, bg.by0, bg.cell);
+    if (cx < -1 || cx > bg.nbx || cy < -1 || cy > bg.nby) return;
+    kb = (type - 1) * dir_slab + cy * bg.nbx + cx;
+    #pragma unroll
+    for (int q = 0; q < 9; q++) {
+        const long long nx = cx + (q % 3) - 1, ny = cy + (q / 3) - 1;
+        if (nx >= 0 && nx < bg.nbx && ny >= 0 && ny < bg.nby) nbmask |= 1u << q;
+    }
+}
+
+__global__ void __launch_bounds__(CH_THREADS)
 qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGeom bg, int bots_per_graph,
                      int max_agent, int win, int min_between, double r2thr, double corr,
                      double *__restrict__ drift, long long *__restrict__ last_closure,
                      unsigned long long *__restrict__ counters)
 {
-    const int g = blockIdx.x, lane = threadIdx.x;
+    const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     QsGraphDev G = graphs[g];
     const int bot0 = g * bots_per_graph + 1;
     const int nb = min(bots_per_graph, max_agent - bot0 + 1);
@@ -174,120 +209,146 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
     __shared__ double s_drift[QS_MAX_AGENT + 1][2];
     __shared__ long long s_last[QS_MAX_AGENT + 1];
     __shared__ unsigned int s_acnt[QS_MAX_AGENT + 1];
-    __shared__ long long s_bidx[QS_WAVE];
-    __shared__ double s_bx[QS_WAVE], s_by[QS_WAVE];
-    __shared__ long long s_ridx[32];
-    __shared__ double s_rx[32], s_ry[32];
+    __shared__ long long w_idx[32], w_kb[32], w_ridx[32];
+    __shared__ double w_x[32], w_y[32], w_rx[32], w_ry[32];
+    __shared__ int w_type[32];
+    __shared__ unsigned int w_nbm[32];
+    __shared__ long long n_idx[32];            // next window's events, prefetched by the last wave
+    __shared__ double n_px[32], n_py[32];
+    __shared__ int n_a[32], n_type[32];
+    __shared__ int s_k;
+    __shared__ unsigned long long s_emask;
+    __shared__ long long s_nmisc;
 
-    for (int t = lane; t < nb; t += QS_WAVE) {
+    for (int t = tid; t < nb; t += CH_THREADS) {
         s_drift[t][0] = drift[2 * (bot0 + t)];
         s_drift[t][1] = drift[2 * (bot0 + t) + 1];
         s_last[t] = last_closure[bot0 + t];
         s_acnt[t] = 0;
     }
+    if (tid == 0) s_nmisc = G.n_misc;
     __syncthreads();
 
     const unsigned int e0 = sb.ev_base[g], e1 = sb.ev_base[g + 1];
-    long long n_lms = G.n_lms, n_cls = G.n_cls, n_misc = G.n_misc;
+    long long n_lms = G.n_lms, n_cls = G.n_cls, n_misc = G.n_misc;     // authoritative in wave 0
     unsigned int pool = G.nodes_used;
     const long long dir_slab = (long long)bg.nbx * bg.nby;
+    unsigned long long st_windows = 0, st_rounds = 0, st_iters = 0, st_misc = 0;
+    const unsigned long long t0_cyc = __builtin_amdgcn_s_memtime(), t0_real = __builtin_amdgcn_s_memrealtime();
+
+    // registers of wave 0 that live across the phases of one window
+    long long idx = LL_MAX, kb = -1, first = 0;
+    int a = 0, type = 0;
+    double px = 0, py = 0, x = 0, y = 0;
+    unsigned int nbm = 0;
+    bool inw = false, elig = false;
+
+    if (wave == CH_WAVES - 1 && lane < 32) {
+        const bool have = e0 + lane < e1;
+        n_idx[lane] = have ? sb.ev_node[e0 + lane] : LL_MAX;
+        n_a[lane] = have ? sb.ev_agent[e0 + lane] : 0; n_type[lane] = have ? sb.ev_type[e0 + lane] : 0;
+        n_px[lane] = have ? sb.ev_px[e0 + lane] : 0; n_py[lane] = have ? sb.ev_py[e0 + lane] : 0;
+    }
+    __syncthreads();
+    QsDirEntry de = {0, 0, 0, 0};
 
     for (unsigned int e = e0; e < e1;) {
-        // ---- window: the next events whose node index is < first + win ---------------------------
-        const bool have = lane < 32 && e + lane < e1;
-        long long idx = have ? sb.ev_node[e + lane] : LL_MAX;
-        const long long first = __shfl(idx, 0);
-        const bool inw = have && idx < first + win;
-        const int k = __popcll(__ballot(inw));                  // a contiguous prefix of the lanes
-        int a = 0, type = 0;
-        double px = 0, py = 0;
-        if (inw) { a = sb.ev_agent[e + lane]; type = sb.ev_type[e + lane]; px = sb.ev_px[e + lane]; py = sb.ev_py[e + lane]; }
-        double x = px + s_drift[a][0];                          // rx += cdx  :856
-        double y = py + s_drift[a][1];                          // ry += cdy  :857
-        const bool elig = inw && (idx - s_last[a] >= min_between);                     // :304
-        const unsigned long long emask = __ballot(elig);
-        if (lane < 32) s_ridx[lane] = LL_MAX;
-        __syncthreads();
-
-        // ---- queries: 9 lanes (the 3x3 buckets) per eligible event, 7 events per round -----------
-        const int n_elig = __popcll(emask);
-        for (int round = 0; round * 7 < n_elig; round++) {
-            const int gq = lane / 9, nbk = lane % 9;
-            const int src = lane < 63 ? nth_set_bit(emask, round * 7 + gq) : -1;
-            const bool active = src >= 0;
-            const int sl = active ? src : 0;
-            const double qx = __shfl(x, sl), qy = __shfl(y, sl);
-            const int qtype = __shfl(type, sl);
-            const long long limit = __shfl(idx, sl) - min_between;                     // :300
-            unsigned int node = 0;
-            if (active && qtype >= 1 && qtype <= QS_NTYPES) {
-                const long long cx = bucket_coord(qx, bg.bx0, bg.cell) + (nbk % 3) - 1;
-                const long long cy = bucket_coord(qy, bg.by0, bg.cell) + (nbk / 3) - 1;
-                if (cx >= 0 && cx < bg.nbx && cy >= 0 && cy < bg.nby)
-                    node = G.dir[(qtype - 1) * dir_slab + cy * bg.nbx + cx].head;
+        // ---- phase A (wave 0): the next events whose node index is < first + win ---------------------
+        if (wave == 0) {
+            const bool have = lane < 32 && e + lane < e1;
+            idx = LL_MAX; a = 0; type = 0; px = 0; py = 0;
+            if (have) { idx = n_idx[lane]; a = n_a[lane]; type = n_type[lane]; px = n_px[lane]; py = n_py[lane]; }
+            first = rl64(idx, 0);
+            inw = have && idx < first + win;                        // a contiguous prefix of the lanes
+            if (!inw) { a = 0; type = 0; }
+            x = px + s_drift[a][0];                                 // rx += cdx  :856
+            y = py + s_drift[a][1];                                 // ry += cdy  :857
+            elig = inw && (idx - s_last[a] >= min_between);         // :304
+            bucket_prepare(x, y, type, bg, dir_slab, kb, nbm);
+            if (lane < 32) {
+                w_idx[lane] = idx; w_x[lane] = x; w_y[lane] = y; w_type[lane] = type;
+                w_kb[lane] = kb; w_nbm[lane] = nbm; w_ridx[lane] = LL_MAX;
             }
-            long long best = LL_MAX;
-            double bx = 0, by = 0;
-            while (__ballot(node != 0)) {
-                bool stop = false, found = false;
-                unsigned int nxt = 0;
-                long long last_idx = LL_MAX;
-                if (node) {
-                    const QsLmNode *nd = G.nodes + node;
-                    long long id[QS_NODE_CAP]; double nx[QS_NODE_CAP], ny[QS_NODE_CAP];
-                    #pragma unroll
-                    for (int s = 0; s < QS_NODE_CAP; s++) { id[s] = nd->idx[s]; nx[s] = nd->x[s]; ny[s] = nd->y[s]; }
-                    nxt = G.nd_next[node];
-                    last_idx = id[QS_NODE_CAP - 1];
-                    #pragma unroll
-                    for (int s = 0; s < QS_NODE_CAP; s++) {
-                        if (!found && !stop) {
-                            if (id[s] > limit) stop = true;     // later entries are later nodes still
-                            else {
-                                const double dx = qx - nx[s], dy = qy - ny[s];
-                                if (dx * dx + dy * dy < r2thr) { found = true; best = id[s]; bx = nx[s]; by = ny[s]; }   // :308-309
-                            }
-                        }
-                    }
-                }
-                s_bidx[lane] = best;
-                __syncthreads();
-                long long gbest = LL_MAX;
-                if (lane < 63) {
-                    #pragma unroll
-                    for (int q = 0; q < 9; q++) { const long long v = s_bidx[gq * 9 + q]; gbest = v < gbest ? v : gbest; }
-                }
-                __syncthreads();
-                if (node) node = (found || stop || nxt == 0 || last_idx >= gbest) ? 0u : nxt;
-            }
-            // deliver the group's first match (lowest node index) to the event's lane
-            s_bidx[lane] = best; s_bx[lane] = bx; s_by[lane] = by;
-            __syncthreads();
-            if (active && nbk == 0) {
-                long long m = LL_MAX; double mx = 0, my = 0;
-                #pragma unroll
-                for (int q = 0; q < 9; q++) {
-                    const long long v = s_bidx[gq * 9 + q];
-                    if (v < m) { m = v; mx = s_bx[gq * 9 + q]; my = s_by[gq * 9 + q]; }
-                }
-                s_ridx[src] = m; s_rx[src] = mx; s_ry[src] = my;
-            }
-            __syncthreads();
+            const unsigned long long em = __ballot(elig);
+            const int kw = __popcll(__ballot(inw));
+            if (lane == 0) { s_k = kw; s_emask = em; }
+            st_windows++;
         }
-        // ---- landmarks outside the directory: linear scan in insertion order (rare) ---------------
-        if (n_misc > 0) {
-            unsigned long long rem = emask;
-            while (rem) {
-                const int src = __ffsll((long long)rem) - 1;
-                rem &= rem - 1;
-                const double qx = __shfl(x, src), qy = __shfl(y, src);
-                const int qtype = __shfl(type, src);
-                const long long limit = __shfl(idx, src) - min_between;
-                for (long long c0 = 0; c0 < n_misc; c0 += QS_WAVE) {
+        lds_barrier();
+        const int k = s_k;
+        const unsigned long long emask = s_emask;
+        // the last wave fetches the next window's events while the queries run
+        long long f_idx = LL_MAX; int f_a = 0, f_type = 0; double f_px = 0, f_py = 0;
+        const bool fetcher = wave == CH_WAVES - 1 && lane < 32;
+        if (fetcher && e + k + lane < e1) {
+            const unsigned int q = e + k + lane;
+            f_idx = sb.ev_node[q]; f_a = sb.ev_agent[q]; f_type = sb.ev_type[q]; f_px = sb.ev_px[q]; f_py = sb.ev_py[q];
+        }
+        // wave 0 fetches the directory entries its inserts will need (re-posed lanes reload later)
+        if (wave == 0) {
+            de = QsDirEntry{0, 0, 0, 0};
+            if (inw && kb >= 0 && ((nbm >> 4) & 1u)) de = G.dir[kb];
+        }
+
+        // ---- phase B (all waves): one eligible event per wave at a time.  lane = (bucket of the
+        // 3x3 neighbourhood, entry of that bucket's current 7-entry node): a node scan is three
+        // coalesced row loads (idx, x, y of 9 nodes) ---------------------------------------------------
+        {
+            int qn = 0;
+            for (unsigned long long qrem = emask; qrem; qrem &= qrem - 1, qn++) {
+                if (qn % CH_WAVES != wave) continue;
+                const int src = __ffsll((long long)qrem) - 1;
+                const int nbk = lane / QS_NODE_CAP, se = lane % QS_NODE_CAP;
+                const int last_lane = min(nbk * QS_NODE_CAP + QS_NODE_CAP - 1, 63);
+                const double qx = w_x[src], qy = w_y[src];
+                const int qtype = w_type[src];
+                const long long limit = w_idx[src] - min_between;                  // :300
+                const long long qkb = w_kb[src];
+                const unsigned int qnbm = w_nbm[src];
+                unsigned int node = 0;
+                if (lane < 9 * QS_NODE_CAP && ((qnbm >> nbk) & 1u))
+                    node = G.dir[qkb + ((nbk / 3) - 1) * (long long)bg.nbx + (nbk % 3) - 1].head;
+                long long best = LL_MAX, gbest = LL_MAX;
+                double bx = 0, by = 0;
+                st_rounds++;
+                while (__ballot(node != 0)) {
+                    st_iters++;
+                    long long id = LL_MAX;
+                    double nx = 0, ny = 0;
+                    unsigned int nxt = 0;
+                    if (node) { const QsLmNode *nd = G.nodes + node; id = nd->idx[se]; nx = nd->x[se]; ny = nd->y[se]; nxt = G.nd_next[node]; }
+                    const bool inlim = node != 0 && id <= limit;      // empty slots read as a huge index
+                    bool newhit = false;
+                    if (inlim && best == LL_MAX) {
+                        const double dx = qx - nx, dy = qy - ny;
+                        if (dx * dx + dy * dy < r2thr) { best = id; bx = nx; by = ny; newhit = true; }   // :308-309
+                    }
+                    for (unsigned long long hm = __ballot(newhit); hm; hm &= hm - 1) {
+                        const long long v = rl64(best, __ffsll((long long)hm) - 1);
+                        gbest = v < gbest ? v : gbest;
+                    }
+                    const unsigned long long hitm = __ballot(best != LL_MAX);
+                    const unsigned long long limm = __ballot(inlim);
+                    const long long lastid = __shfl(id, last_lane);
+                    // a bucket's chain goes on only if none of its entries matched, its node was full
+                    // and within the limit, and its last entry is still older than the best match
+                    const bool b_hit = ((hitm >> (nbk * QS_NODE_CAP)) & 0x7full) != 0;
+                    const bool b_full = ((limm >> last_lane) & 1ull) != 0;
+                    if (node) node = (b_hit || !b_full || nxt == 0 || lastid >= gbest) ? 0u : nxt;
+                }
+                double wx = 0, wy = 0;
+                if (gbest != LL_MAX) {                                  // uniform
+                    const int w = __ffsll((long long)__ballot(best == gbest)) - 1;
+                    wx = __shfl(bx, w); wy = __shfl(by, w);
+                }
+                // landmarks outside the directory: linear scan in insertion order (rare)
+                const long long nm = s_nmisc;
+                for (long long c0 = 0; c0 < nm; c0 += QS_WAVE) {
+                    st_misc++;
                     const long long k2 = c0 + lane;
                     bool cand = false, beyond = false;
                     long long li = LL_MAX; double lx = 0, ly = 0;
-                    if (k2 < n_misc) {
+                    if (k2 < nm) {
                         const unsigned int slot = G.misc[k2];
                         li = G.lm_idx[slot];
                         beyond = li > limit;
@@ -300,124 +361,131 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
                     const unsigned long long cm = __ballot(cand);
                     if (cm) {
                         const int w = __ffsll((long long)cm) - 1;
-                        const long long widx = __shfl(li, w);
-                        const double wx = __shfl(lx, w), wy = __shfl(ly, w);
-                        if (lane == 0 && widx < s_ridx[src]) { s_ridx[src] = widx; s_rx[src] = wx; s_ry[src] = wy; }
+                        const long long widx = rl64(li, w);
+                        if (widx < gbest) { gbest = widx; wx = __shfl(lx, w); wy = __shfl(ly, w); }
                         break;
                     }
                     if (__ballot(beyond)) break;
                 }
-                __syncthreads();
+                if (lane == 0 && gbest != LL_MAX) { w_ridx[src] = gbest; w_rx[src] = wx; w_ry[src] = wy; }
             }
         }
-        const long long m_idx = lane < 32 ? s_ridx[lane] : LL_MAX;
-        const double m_x = lane < 32 ? s_rx[lane] : 0, m_y = lane < 32 ? s_ry[lane] : 0;
-        const bool matched = elig && m_idx != LL_MAX;
+        if (fetcher) { n_idx[lane] = f_idx; n_a[lane] = f_a; n_type[lane] = f_type; n_px[lane] = f_px; n_py[lane] = f_py; }
+        lds_barrier();
 
-        // ---- resolve: per agent, its first eligible event with a match closes the loop ------------
-        bool closes = matched;
-        {
-            unsigned long long rem = __ballot(matched);
-            while (rem) {
+        // ---- phase C (wave 0): commit, in node order ------------------------------------------------------
+        if (wave == 0) {
+            const long long m_idx = lane < 32 ? w_ridx[lane] : LL_MAX;
+            const double m_x = lane < 32 ? w_rx[lane] : 0, m_y = lane < 32 ? w_ry[lane] : 0;
+            const bool matched = elig && m_idx != LL_MAX;
+            // per agent, its first eligible event with a match closes the loop
+            bool closes = matched;
+            for (unsigned long long rem = __ballot(matched); rem;) {
                 const int c = __ffsll((long long)rem) - 1;
-                const int ac = __shfl(a, c);
+                const int ac = __builtin_amdgcn_readlane(a, c);
                 const unsigned long long same = __ballot(matched && a == ac);
                 if (matched && a == ac && lane != c) closes = false;
                 rem &= ~same;
             }
-        }
-        const unsigned long long cmask = __ballot(closes);
-        if (closes) {
-            const double ex = m_x - x, ey = m_y - y;                                   // :311-312
-            const double cdx = ex * corr, cdy = ey * corr;                             // :314-315
-            const double ndx = s_drift[a][0] + cdx, ndy = s_drift[a][1] + cdy;         // :911-914
-            const long long slot = n_cls + __popcll(cmask & ((1ull << lane) - 1));
-            if (slot < G.cap_cls) {
-                G.cl_lm_idx[slot] = m_idx; G.cl_node_idx[slot] = idx;                  // :317
-                G.cl_dx[slot] = cdx; G.cl_dy[slot] = cdy;
+            const unsigned long long cmask = __ballot(closes);
+            if (closes) {
+                const double ex = m_x - x, ey = m_y - y;                                   // :311-312
+                const double cdx = ex * corr, cdy = ey * corr;                             // :314-315
+                const double ndx = s_drift[a][0] + cdx, ndy = s_drift[a][1] + cdy;         // :911-914
+                const long long slot = n_cls + __popcll(cmask & ((1ull << lane) - 1));
+                if (slot < G.cap_cls) {
+                    G.cl_lm_idx[slot] = m_idx; G.cl_node_idx[slot] = idx;                  // :317
+                    G.cl_dx[slot] = cdx; G.cl_dy[slot] = cdy;
+                }
+                const unsigned int pos = sb.agent_ev[bot0 + a] + s_acnt[a];
+                sb.acl_node[pos] = idx; sb.acl_dx[pos] = ndx; sb.acl_dy[pos] = ndy;
+                s_acnt[a] = s_acnt[a] + 1;
+                s_drift[a][0] = ndx; s_drift[a][1] = ndy;
+                s_last[a] = idx;                                                           // :318
             }
-            const unsigned int pos = sb.agent_ev[bot0 + a] + s_acnt[a];
-            sb.acl_node[pos] = idx; sb.acl_dx[pos] = ndx; sb.acl_dy[pos] = ndy;
-            s_acnt[a] = s_acnt[a] + 1;
-            s_drift[a][0] = ndx; s_drift[a][1] = ndy;
-            s_last[a] = idx;                                                           // :318
-        }
-        n_cls += __popcll(cmask);
-        __syncthreads();
-        // later events of a closing agent in this window are posed (and stored) with the new drift
-        if (inw && !closes && s_last[a] >= first && s_last[a] < idx) {
-            x = px + s_drift[a][0];
-            y = py + s_drift[a][1];
-        }
-
-        // ---- self.landmarks.append((x, y, landmark_type, idx))  :288 -----------------------------
-        const long long log_slot = n_lms + lane;
-        if (inw && log_slot < G.cap_lms) {
-            G.lm_x[log_slot] = x; G.lm_y[log_slot] = y; G.lm_idx[log_slot] = idx; G.lm_type[log_slot] = (unsigned char)type;
-        }
-        // spatial index insert: events of one bucket are appended in lane (= node) order
-        long long key = -1;
-        if (inw && type >= 1 && type <= QS_NTYPES) {
-            const long long cx = bucket_coord(x, bg.bx0, bg.cell), cy = bucket_coord(y, bg.by0, bg.cell);
-            if (cx >= 0 && cx < bg.nbx && cy >= 0 && cy < bg.nby) key = (type - 1) * dir_slab + cy * bg.nbx + cx;
-        }
-        const bool inb = key >= 0;
-        const bool is_misc = inw && !inb;
-        {
-            const unsigned long long mm = __ballot(is_misc);
-            if (is_misc) G.misc[n_misc + __popcll(mm & ((1ull << lane) - 1))] = (unsigned int)log_slot;
-            n_misc += __popcll(mm);
-        }
-        QsDirEntry de = {0, 0, 0, 0};
-        if (inb) de = G.dir[key];
-        unsigned long long rem = __ballot(inb);
-        while (rem) {
-            const int ld = __ffsll((long long)rem) - 1;
-            const long long kk = __shfl(key, ld);
-            const unsigned long long grp = __ballot(inb && key == kk);
-            const int gsize = __popcll(grp);
-            const unsigned int head = __shfl(de.head, ld), tail = __shfl(de.tail, ld);
-            const unsigned int tc = head ? __shfl(de.tail_cnt, ld) : QS_NODE_CAP;   // no tail node yet: "full"
-            const unsigned int total = tc + gsize;
-            const unsigned int nn = total > QS_NODE_CAP ? (total - QS_NODE_CAP + QS_NODE_CAP - 1) / QS_NODE_CAP : 0;
-            const unsigned int base = pool;
-            if (inb && key == kk) {
-                const unsigned int p = tc + __popcll(grp & ((1ull << lane) - 1));
-                const unsigned int nd = p < QS_NODE_CAP ? tail : base + (p - QS_NODE_CAP) / QS_NODE_CAP;
-                const unsigned int sl = p < QS_NODE_CAP ? p : (p - QS_NODE_CAP) % QS_NODE_CAP;
-                QsLmNode *np = G.nodes + nd;
-                np->idx[sl] = idx; np->x[sl] = x; np->y[sl] = y;
-                if (lane == ld) {
-                    QsDirEntry upd;
-                    upd.head = head; upd.tail = tail; upd.tail_cnt = total; upd.pad = 0;
-                    if (nn) {
-                        for (unsigned int q = 0; q + 1 < nn; q++) G.nd_next[base + q] = base + q + 1;
-                        if (head) G.nd_next[tail] = base; else upd.head = base;
-                        upd.tail = base + nn - 1;
-                        upd.tail_cnt = total - QS_NODE_CAP * nn;
-                    }
-                    G.dir[kk] = upd;
+            n_cls += __popcll(cmask);
+            if (cmask) {
+                // later events of a closing agent in this window are posed (and stored) with the new drift
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                if (inw && !closes && s_last[a] >= first && s_last[a] < idx) {
+                    x = px + s_drift[a][0];
+                    y = py + s_drift[a][1];
+                    bucket_prepare(x, y, type, bg, dir_slab, kb, nbm);
+                    de = QsDirEntry{0, 0, 0, 0};
+                    if (kb >= 0 && ((nbm >> 4) & 1u)) de = G.dir[kb];
                 }
             }
-            pool += nn;
-            rem &= ~grp;
+            // self.landmarks.append((x, y, landmark_type, idx))  :288
+            const long long log_slot = n_lms + lane;
+            if (inw && log_slot < G.cap_lms) {
+                G.lm_x[log_slot] = x; G.lm_y[log_slot] = y; G.lm_idx[log_slot] = idx; G.lm_type[log_slot] = (unsigned char)type;
+            }
+            // spatial index insert: events of one bucket are appended in lane (= node) order
+            const bool inb = inw && kb >= 0 && ((nbm >> 4) & 1u);      // the centre bucket exists
+            const long long key = inb ? kb : -1;
+            const bool is_misc = inw && !inb;
+            {
+                const unsigned long long mm = __ballot(is_misc);
+                if (is_misc && log_slot < G.cap_lms) G.misc[n_misc + __popcll(mm & ((1ull << lane) - 1))] = (unsigned int)log_slot;
+                n_misc += __popcll(mm);
+            }
+            for (unsigned long long rem = __ballot(inb); rem;) {
+                const int ld = __ffsll((long long)rem) - 1;
+                const long long kk = rl64(key, ld);
+                const unsigned long long grp = __ballot(inb && key == kk);
+                const int gsize = __popcll(grp);
+                const unsigned int head = __builtin_amdgcn_readlane(de.head, ld), tail = __builtin_amdgcn_readlane(de.tail, ld);
+                const unsigned int tc = head ? __builtin_amdgcn_readlane(de.tail_cnt, ld) : QS_NODE_CAP;   // no tail node yet: "full"
+                const unsigned int total = tc + gsize;
+                const unsigned int nn = total > QS_NODE_CAP ? (total - QS_NODE_CAP + QS_NODE_CAP - 1) / QS_NODE_CAP : 0;
+                const unsigned int base = pool;
+                if (inb && key == kk && (long long)base + nn <= G.cap_lms) {
+                    const unsigned int p = tc + __popcll(grp & ((1ull << lane) - 1));
+                    const unsigned int nd = p < QS_NODE_CAP ? tail : base + (p - QS_NODE_CAP) / QS_NODE_CAP;
+                    const unsigned int sl = p < QS_NODE_CAP ? p : (p - QS_NODE_CAP) % QS_NODE_CAP;
+                    QsLmNode *np = G.nodes + nd;
+                    np->idx[sl] = idx; np->x[sl] = x; np->y[sl] = y;
+                    if (lane == ld) {
+                        QsDirEntry upd;
+                        upd.head = head; upd.tail = tail; upd.tail_cnt = total; upd.pad = 0;
+                        if (nn) {
+                            for (unsigned int q = 0; q + 1 < nn; q++) G.nd_next[base + q] = base + q + 1;
+                            if (head) G.nd_next[tail] = base; else upd.head = base;
+                            upd.tail = base + nn - 1;
+                            upd.tail_cnt = total - QS_NODE_CAP * nn;
+                        }
+                        G.dir[kk] = upd;
+                    }
+                }
+                pool += nn;
+                rem &= ~grp;
+            }
+            n_lms += k;
+            if (lane == 0) s_nmisc = n_misc;
         }
-        n_lms += k;
         e += k;
-        // stores of this window (landmarks, directory) are ordered before the next window's loads
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        // this window's stores (landmarks, directory) are ordered before the next window's loads
         __syncthreads();
     }
 
-    for (int t = lane; t < nb; t += QS_WAVE) {
+    for (int t = tid; t < nb; t += CH_THREADS) {
         drift[2 * (bot0 + t)] = s_drift[t][0];
         drift[2 * (bot0 + t) + 1] = s_drift[t][1];
         last_closure[bot0 + t] = s_last[t];
         sb.acl_cnt[bot0 + t] = s_acnt[t];
     }
+    // per-wave statistics, wave 0's bookkeeping
     if (lane == 0) {
+        atomicAdd(&counters[QS_CNT_SLAM_ROUNDS], st_rounds);
+        atomicAdd(&counters[QS_CNT_SLAM_NODE_ITERS], st_iters);
+        atomicAdd(&counters[QS_CNT_SLAM_MISC_ITERS], st_misc);
+    }
+    if (tid == 0) {
         atomicAdd(&counters[QS_CNT_CLOSURES], (unsigned long long)(n_cls - G.n_cls));
         atomicAdd(&counters[QS_CNT_LANDMARKS], (unsigned long long)(n_lms - G.n_lms));
+        atomicAdd(&counters[QS_CNT_SLAM_WINDOWS], st_windows);
+        atomicAdd(&counters[QS_CNT_SLAM_CYCLES], __builtin_amdgcn_s_memtime() - t0_cyc);
+        atomicAdd(&counters[QS_CNT_SLAM_REALTIME], __builtin_amdgcn_s_memrealtime() - t0_real);
         graphs[g].n_nodes = G.n_nodes + sb.acc_total[g];
         graphs[g].n_lms = n_lms;
         graphs[g].n_cls = n_cls;
@@ -458,7 +526,7 @@ hipError_t qs_launch_slam(qs_ctx *c, size_t n)
     hipLaunchKernelGGL(qs_slam_prefix_kernel, dim3(1), dim3(256), 0, c->stream, sb, G, c->cfg.max_agent, c->d_drift);
     hipLaunchKernelGGL(qs_slam_index_kernel, dim3(sb.n_blocks), dim3(IDX_BLOCK), (size_t)IDX_WAVES * G * 2 * sizeof(unsigned int),
                        c->stream, n, c->b, sb, c->d_graphs, c->bots_per_graph, G);
-    hipLaunchKernelGGL(qs_slam_chain_kernel, dim3(G), dim3(QS_WAVE), 0, c->stream, c->d_graphs, sb, c->bg,
+    hipLaunchKernelGGL(qs_slam_chain_kernel, dim3(G), dim3(CH_THREADS), 0, c->stream, c->d_graphs, sb, c->bg,
                        c->bots_per_graph, c->cfg.max_agent, c->win, c->cfg.min_poses_between, c->r2_threshold,
                        c->cfg.closure_correction, c->d_drift, c->d_last_closure, c->d_counters);
     hipLaunchKernelGGL(qs_slam_pose_kernel, dim3((unsigned int)((n + 255) / 256)), dim3(256), 0, c->stream, n, c->b, sb);

@@ -65,6 +65,8 @@ typedef struct {
     /* per valid hit log, arrival order */
     double *hit; int32_t *hit_agent_sensor; long n_hit, cap_hit;
     long n_rays, n_cells_written, n_datagrams;
+    /* optional per-bot EKF on the build-defined telemetry wiring (see qso_ekf_packet) */
+    int ekf_on; double ekf_mpt, cur_time; double *ekf, *ekf_prev;
 } mapper_t;
 
 /* ---- OccupancyGrid ---------------------------------------------------------------- */
@@ -179,11 +181,22 @@ void qso_destroy(mapper_t *m)
     for (int g = 0; g < m->n_graphs; g++) { free(m->graphs[g].lms); free(m->graphs[g].cls); }
     free(m->grid); free(m->hits); free(m->misses); free(m->graphs); free(m->offset_x);
     free(m->drift); free(m->last_closure); free(m->zone); free(m->zone_n); free(m->pkt_count);
+    free(m->ekf); free(m->ekf_prev);
     free(m->pose); free(m->pose_agent); free(m->pose_src); free(m->hit); free(m->hit_agent_sensor);
     free(m);
 }
 
 void qso_set_offset(mapper_t *m, int bot, double off_x) { m->offset_x[bot] = off_x; }
+
+void qso_ekf_packet(double *f, double *prev, double t, double x, double y, double yaw,
+                    double enc, double metres_per_tick);
+
+void qso_enable_ekf(mapper_t *m, double metres_per_tick)
+{
+    m->ekf_on = 1; m->ekf_mpt = metres_per_tick;
+    if (!m->ekf) { m->ekf = calloc((size_t)(m->max_agent + 1) * 44, sizeof(double)); m->ekf_prev = calloc((size_t)(m->max_agent + 1) * 4, sizeof(double)); }
+}
+const double *qso_ekf_state(const mapper_t *m, int bot) { return m->ekf + (size_t)bot * 44; }
 
 static void zone_fold(mapper_t *m, int bot, double x, double y)
 {   /* compute_bounding_box :702-706 over point_clouds[bot] U paths[bot] (:930-940); the
@@ -214,6 +227,11 @@ int qso_feed(mapper_t *m, const uint8_t *d, int len)
     if (!isfinite(rx) || !isfinite(ry) || !isfinite(ryaw)) return 0;
     m->pkt_count[agent]++;                               /* :848 */
     rx += m->offset_x[agent];  /* :851-852 (bot 2: separation; x + 0.0 is exact for the others) */
+    if (m->ekf_on) {   /* telemetry only: uses the pose before drift correction, never feeds the map */
+        int32_t enc; memcpy(&enc, d + 17, 4);
+        qso_ekf_packet(m->ekf + (size_t)agent * 44, m->ekf_prev + (size_t)agent * 4, m->cur_time, rx, ry, ryaw,
+                       (double)enc, m->ekf_mpt);
+    }
     rx += m->drift[2 * agent];                           /* :855-857 */
     ry += m->drift[2 * agent + 1];
     zone_fold(m, agent, rx, ry);                         /* paths  :878-879 */
@@ -259,8 +277,22 @@ int qso_feed(mapper_t *m, const uint8_t *d, int len)
 long qso_feed_stream(mapper_t *m, const uint8_t *buf, long n, long stride, const uint16_t *lens)
 {
     long acc = 0;
-    for (long i = 0; i < n; i++)
+    for (long i = 0; i < n; i++) {
+        m->cur_time = (double)(m->n_datagrams);
         acc += qso_feed(m, buf + i * stride, lens ? lens[i] : (int)stride);
+    }
+    return acc;
+}
+
+/* same with receive times (seconds) for the EKF wiring */
+long qso_feed_stream_t(mapper_t *m, const uint8_t *buf, long n, long stride, const uint16_t *lens,
+                       const double *times)
+{
+    long acc = 0;
+    for (long i = 0; i < n; i++) {
+        m->cur_time = times ? times[i] : (double)(m->n_datagrams);
+        acc += qso_feed(m, buf + i * stride, lens ? lens[i] : (int)stride);
+    }
     return acc;
 }
 

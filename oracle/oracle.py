@@ -39,6 +39,11 @@ def lib():
         L.qso_feed.argtypes = [vp, vp, i32]
         L.qso_feed_stream.restype = i64
         L.qso_feed_stream.argtypes = [vp, vp, i64, i64, vp]
+        L.qso_feed_stream_t.restype = i64
+        L.qso_feed_stream_t.argtypes = [vp, vp, i64, i64, vp, vp]
+        L.qso_enable_ekf.argtypes = [vp, f64]
+        L.qso_ekf_state.restype = vp
+        L.qso_ekf_state.argtypes = [vp, i32]
         L.qso_update_rays.argtypes = [vp, vp, vp, vp, vp, vp, i64]
         L.qso_world_to_grid.argtypes = [vp, vp, i64, i32, vp]
         L.qso_bresenham.restype = i64
@@ -107,15 +112,25 @@ class OracleMapper:
         b = np.frombuffer(datagram, dtype=np.uint8) if len(datagram) else np.zeros(1, np.uint8)
         return lib().qso_feed(self._h, _ptr(b), len(datagram))
 
-    def feed_stream(self, buf, lengths=None) -> int:
-        """buf: uint8 [n, stride]; lengths: uint16 [n] or None (all == stride)."""
+    def feed_stream(self, buf, lengths=None, times=None) -> int:
+        """buf: uint8 [n, stride]; lengths: uint16 [n] or None (all == stride); times: float64 [n]."""
         buf = np.ascontiguousarray(buf, dtype=np.uint8)
         n, stride = buf.shape
         lp = None
         if lengths is not None:
             lengths = np.ascontiguousarray(lengths, dtype=np.uint16)
             lp = _ptr(lengths)
+        if times is not None:
+            times = np.ascontiguousarray(times, dtype=np.float64)
+            return lib().qso_feed_stream_t(self._h, _ptr(buf), n, stride, lp, _ptr(times))
         return lib().qso_feed_stream(self._h, _ptr(buf), n, stride, lp)
+
+    def enable_ekf(self, metres_per_tick=0.0107):
+        lib().qso_enable_ekf(self._h, metres_per_tick)
+
+    def ekf_state(self, bot):
+        f = _view(lib().qso_ekf_state(self._h, bot), (44,), np.float64)
+        return f[:6], f[6:42].reshape(6, 6)
 
     def update_rays(self, rx, ry, hx, hy, valid):
         a = [np.ascontiguousarray(v, dtype=np.float64) for v in (rx, ry, hx, hy)]

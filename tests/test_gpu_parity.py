@@ -156,3 +156,66 @@ def test_reset_starts_a_new_session(pkg):
         m.ingest_array(g["datagrams"], g["lengths"])
         assert hashlib.sha256(m.grid_i8().tobytes()).digest() == g["grid_sha256"].tobytes()
         assert (m.closures(0)[0] == g["closures_idx"]).all()
+
+
+def _oracle_ekf_over_stream(g, metres_per_tick=0.0107):
+    """The build-defined EKF wiring (oracle.c:qso_ekf_packet) over a golden datagram stream."""
+    import struct as _st
+    ek = orc.OracleEKF(3)
+    sep = g["cfg"][4]
+    for i, (d, n) in enumerate(zip(g["datagrams"], g["lengths"])):
+        if not g["accepted"][i]:
+            continue
+        f = _st.unpack("<4sBfffiIffff", d[:41].tobytes())
+        agent, x, y, yaw, enc = f[1], f[2], f[3], f[4], f[5]
+        px = float(np.float32(x)) + (sep if agent == 2 else 0.0)
+        ek.packet(agent, float(g["recv_time"][i]), px, float(np.float32(y)), float(np.float32(yaw)), float(enc),
+                  metres_per_tick)
+    return ek
+
+
+def test_ekf_ingest_matches_oracle(pkg):
+    """EKF (A7) is "parity unpinned" against the reference (Arduino/Eigen, no vectors exist): the HIP
+    filter is checked against the build's own CPU restatement of ekf.cpp, tolerance 1e-5 (north_star),
+    expected ~1e-12."""
+    g = load("session_512")
+    ek = _oracle_ekf_over_stream(g)
+    with make_mapper(pkg, g, enable_ekf=True) as m:
+        m.ingest_array(g["datagrams"], g["lengths"], recv_time=g["recv_time"])
+        for b in (1, 2):
+            x, P = m.ekf_state(b)
+            np.testing.assert_allclose(x, ek.state(b), rtol=0, atol=1e-5)
+            np.testing.assert_allclose(P, ek.cov(b), rtol=0, atol=1e-5)
+            assert np.abs(x - ek.state(b)).max() < 1e-9 and np.abs(P - ek.cov(b)).max() < 1e-9
+    # ragged batches give the same filter state
+    with make_mapper(pkg, g, enable_ekf=True) as m:
+        for lo in range(0, 687, 100):
+            m.ingest_array(g["datagrams"][lo:lo + 100], g["lengths"][lo:lo + 100], recv_time=g["recv_time"][lo:lo + 100])
+        for b in (1, 2):
+            x, P = m.ekf_state(b)
+            assert np.abs(x - ek.state(b)).max() < 1e-9 and np.abs(P - ek.cov(b)).max() < 1e-9
+
+
+def test_ekf_object_api_hand_derived(pkg):
+    """Hand-derived KATs: one predict from x=0, P=I, dt=0.1, omega_m=0.5 gives
+    theta=0.05 and P grown by Q on the diagonal (+ dt^2 coupling); one update with z=[1,0]."""
+    with pkg.QuasarMapper(max_agent=4) as m:
+        for b in (1, 2, 3, 4):
+            m.ekf_init(b, 10.0, np.zeros(6))
+        m.ekf_step([1, 3], [0.5, 0.5], [10.1, 10.1])                       # predict only
+        ek = orc.OracleEKF(5)
+        for b in (1, 3):
+            ek.init(b, 10.0, np.zeros(6)); ek.predict(b, 0.5, 10.1)
+            x, P = m.ekf_state(b)
+            assert abs(x[2] - 0.05) < 1e-15 and x[4] == 0.5 and x[0] == 0 and x[1] == 0
+            np.testing.assert_allclose(x, ek.state(b), rtol=0, atol=1e-12)
+            np.testing.assert_allclose(P, ek.cov(b), rtol=0, atol=1e-12)
+            assert abs(P[0, 0] - (1.0 + 0.1 * 0.1 + 0.01)) < 1e-12      # P00 + (cos*dt)^2*P33 + Q00
+        x2, P2 = m.ekf_state(2)
+        assert (x2 == 0).all() and (P2 == np.eye(6)).all()                  # untouched bot
+        m.ekf_step([1], [0.5], [10.2], z_v=[1.0], z_omega=[0.0])           # predict + update
+        ek.predict(1, 0.5, 10.2); ek.update(1, 1.0, 0.0)
+        x, P = m.ekf_state(1)
+        np.testing.assert_allclose(x, ek.state(1), rtol=0, atol=1e-12)
+        np.testing.assert_allclose(P, ek.cov(1), rtol=0, atol=1e-12)
+        assert 0 < x[3] < 1.0                                               # pulled toward z_v = 1

@@ -16,16 +16,11 @@ def main():
     dev = torch.device("cuda", 0)
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     cases = []
-    cases.append(dict(B=1 << 20, mode=1, counts=True, ekf=False, bots=2))
+    cases.append(dict(B=1 << 18, mode=2, counts=True, ekf=False, bots=2))
     cases.append(dict(B=1 << 20, mode=2, counts=True, ekf=False, bots=2))
-    cases.append(dict(B=1 << 20, mode=2, counts=False, ekf=False, bots=2))
-    cases.append(dict(B=1 << 16, mode=2, counts=True, ekf=False, bots=2))
     cases.append(dict(B=1 << 18, mode=2, counts=True, ekf=True, bots=2))
-    cases.append(dict(B=1 << 20, mode=2, counts=True, ekf=False, bots=64))
-    cases.append(dict(B=1 << 20, mode=2, counts=True, ekf=True, bots=64))
-    cases.append(dict(B=1 << 20, mode=2, counts=True, ekf=False, bots=64, bpg=2))
-    cases.append(dict(B=1 << 20, mode=2, counts=True, ekf=False, bots=0))   # adversarial random stream
-    cases.append(dict(B=1 << 20, mode=1, counts=True, ekf=False, bots=0))
+    cases.append(dict(B=1 << 18, mode=2, counts=True, ekf=False, bots=64))
+    cases.append(dict(B=1 << 20, mode=2, counts=True, ekf=True, bots=64, bpg=2))
     for cs in cases:
         B = cs["B"]
         if cs["bots"] == 2:
@@ -53,7 +48,7 @@ def main():
         cnt = m.counters()
         print(json.dumps({**cs, "ms_per_step": el * 1e3, "Mpkt_s": B / el / 1e6,
                           "stages_ms": {k: round(v[0] / max(v[1], 1), 4) for k, v in st.items() if v[1]},
-                          "cells": cnt["cells"], "closures": cnt["closures"], "landmarks": cnt["landmarks"]}), flush=True)
+                          "cnt": cnt}), flush=True)
         m.close()
         del d, dt
 
