@@ -9,12 +9,12 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libquasar_slam.so")
+LIB_PATH = os.environ.get("QUASAR_SLAM_LIB") or os.path.join(CSRC, "libquasar_slam.so")   # env: A/B builds of the same ABI
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "quasar_slam.h")
 
 QS_CNT_NAMES = ("datagrams", "accepted", "rays", "cells", "hits", "closures", "landmarks", "rebases",
                 "slam_windows", "slam_rounds", "slam_node_iters", "slam_misc_iters", "slam_cycles",
-                "slam_realtime_100mhz")
+                "slam_realtime_100mhz", "slam_cyc_prepare", "slam_cyc_query", "slam_cyc_commit")
 QS_STAGE_NAMES = ("decode", "slam", "raycast", "ekf", "bin")
 UINT64_MAX = (1 << 64) - 1
 

@@ -121,7 +121,8 @@ __device__ inline void ekf_update(EkfState &s, double z_v, double z_omega)   // 
     const double s00 = s.P[3 * 6 + 3] + R0, s01 = s.P[3 * 6 + 4];
     const double s10 = s.P[4 * 6 + 3], s11 = s.P[4 * 6 + 4] + R1;
     const double det = s00 * s11 - s01 * s10;
-    const double i00 = s11 / det, i01 = -s01 / det, i10 = -s10 / det, i11 = s00 / det;
+    const double invdet = 1.0 / det;
+    const double i00 = s11 * invdet, i01 = -s01 * invdet, i10 = -s10 * invdet, i11 = s00 * invdet;
     double K0[6], K1[6];
     #pragma unroll
     for (int r = 0; r < 6; r++) {
@@ -150,16 +151,19 @@ __device__ inline void ekf_update(EkfState &s, double z_v, double z_omega)   // 
 }
 
 // ---- ingest wiring (build-defined; modelled on esp32_firmware/src/main.cpp:176-188) --------
-// Per accepted packet of a bot, in arrival order: first packet initialises the filter at the
-// packet pose; later packets derive omega_m = wrap(yaw - yaw_prev)/dt and
-// v_enc = (enc - enc_prev) * metres_per_tick / dt, then predict(omega_m, t); update(v_enc, omega_m).
+// Per accepted packet of a bot, in arrival order: the first packet initialises the filter at the
+// packet pose; later packets (dt = t - t_prev > 0) derive inv_dt = 1/dt,
+// omega_m = wrap(yaw - yaw_prev) * inv_dt, v_enc = (enc - enc_prev) * metres_per_tick * inv_dt and run
+// predict(omega_m, t); update(v_enc, omega_m).
 //
-// The filter is a strict recurrence per bot, so one wave serves one bot and the 6x6 covariance
-// is spread over 36 lanes: lane l = 6r + c holds P[r][c] and a copy of x[r].  J P J^T needs the
-// column-mates (rows 2,3,5) and then the row-mates (columns 2,3,5) of each element, (I-KH)P the
-// row-mates (columns 3,4) and column-mates (rows 3,4): ten 64-bit shuffles per step instead of
-// ~450 dependent fp64 instructions on one lane.  Every element is evaluated with exactly the
-// operand order of ekf_predict / ekf_update above, so both forms agree bit for bit.
+// The filter is a strict recurrence per bot and a lone wave issues about one instruction every
+// 4-8 cycles, so the serial path is kept short: one wave per bot; everything that does not depend
+// on the filter state (the wiring above, with its division) is done SIMD across the 64 records of
+// a chunk before the serial loop; the 6x6 covariance is spread over 36 lanes (lane l = 6r + c holds
+// P[r][c] and a copy of x[r]) so J P J^T and (I - K H) P cost eight 64-bit lane permutes per step
+// instead of ~450 fp64 instructions on one lane.  Every element is evaluated with the operand order
+// of ekf_predict / ekf_update above (terms that are absent there appear here as + 0.0 * x), so the
+// two forms agree bit for bit.
 #define EKF_BLOCK 256
 
 __device__ inline double ekf_rl(double v, int src_lane)      // wave-uniform read of one lane
@@ -167,6 +171,12 @@ __device__ inline double ekf_rl(double v, int src_lane)      // wave-uniform rea
     int lo = __double2loint(v), hi = __double2hiint(v);
     lo = __builtin_amdgcn_readlane(lo, src_lane);
     hi = __builtin_amdgcn_readlane(hi, src_lane);
+    return __hiloint2double(hi, lo);
+}
+__device__ inline double ekf_perm(double v, int byte_index)   // per-lane read of another lane (index * 4)
+{
+    const int lo = __builtin_amdgcn_ds_bpermute(byte_index, __double2loint(v));
+    const int hi = __builtin_amdgcn_ds_bpermute(byte_index, __double2hiint(v));
     return __hiloint2double(hi, lo);
 }
 
@@ -186,87 +196,102 @@ qs_ekf_ingest_kernel(size_t n, QsBatch b, const double *__restrict__ recv_time, 
     const double Qd[6] = {0.01, 0.01, 0.01, 0.1, 0.1, 0.001};                          // ekf.cpp:11
     const double qdiag = (r == c) ? Qd[r] : 0.0;
     const double R0 = 0.05, R1 = 0.05;                                                  // ekf.cpp:12
+    // lane constants of the permutes (byte indices) and of the term selection
+    const int col_a = 4 * ((r <= 1) ? 12 + c : (r == 2 || r == 4) ? 30 + c : l);   // J P: rows 2 / 5 of my column
+    const int col_b = 4 * ((r <= 1) ? 18 + c : l);                                  //      row 3 of my column
+    const int row_a = 4 * ((c <= 1) ? 6 * r + 2 : (c == 2 || c == 4) ? 6 * r + 5 : l);   // (JP) J^T: cols 2 / 5 of my row
+    const int row_b = 4 * ((c <= 1) ? 6 * r + 3 : l);                                     //           col 3 of my row
+    const int row_3 = 4 * (6 * r + 3), row_4 = 4 * (6 * r + 4), col_3 = 4 * (18 + c), col_4 = 4 * (24 + c);
 
     for (size_t base = 0; base < n; base += QS_WAVE) {
         const size_t i = base + lane;
         const bool mine = i < n && b.accept[i] && b.agent[i] == bot;
         unsigned long long m = __ballot(mine);
         if (!m) continue;
-        // the chunk's fields, one coalesced load per array; each step then reads its record by lane
+        // ---- SIMD prologue: the chunk's fields (one coalesced load per array) and the wiring -------
         double t_l = 0, px_l = 0, py_l = 0, yaw_l = 0, enc_l = 0;
         if (mine) {
             t_l = recv_time ? recv_time[i] : t_nominal0 + (double)i;
             px_l = b.px[i]; py_l = b.py[i]; yaw_l = b.yaw[i]; enc_l = (double)b.enc[i];
         }
+        const unsigned long long below = m & ((1ull << lane) - 1);
+        const int pl = below ? 63 - __clzll((long long)below) : lane;          // previous record of this bot
+        double tp = __shfl(t_l, pl), yawp = __shfl(yaw_l, pl), encp = __shfl(enc_l, pl);
+        const bool chained = below != 0;
+        if (!chained) { tp = pt; yawp = pyaw; encp = penc; }
+        int kind_l = 2;                                                        // 0 init, 1 step, 2 nothing
+        double om_l = 0, ve_l = 0;
+        if (mine) {
+            if (!chained && seen == 0.0) kind_l = 0;
+            else {
+                const double dtp = t_l - tp;
+                if (dtp > 0) {
+                    double dyaw = yaw_l - yawp;
+                    if (dyaw > EKF_PI) dyaw -= 2 * EKF_PI;
+                    else if (dyaw < -EKF_PI) dyaw += 2 * EKF_PI;
+                    const double inv_dt = 1.0 / dtp;
+                    om_l = dyaw * inv_dt;
+                    ve_l = (enc_l - encp) * metres_per_tick * inv_dt;
+                    kind_l = 1;
+                }
+            }
+        }
+        {   // carry the last record of this bot into the next chunk
+            const int hi = 63 - __clzll((long long)m);
+            pt = ekf_rl(t_l, hi); pyaw = ekf_rl(yaw_l, hi); penc = ekf_rl(enc_l, hi); seen = 1.0;
+        }
+        // ---- serial part: one filter step per record, in arrival order ------------------------------
         while (m) {
             const int j = __ffsll((long long)m) - 1;
             m &= m - 1;
-            const double t = ekf_rl(t_l, j), px = ekf_rl(px_l, j), py = ekf_rl(py_l, j), yaw = ekf_rl(yaw_l, j),
-                         enc = ekf_rl(enc_l, j);
-            if (seen == 0.0) {                                    // EKF::EKF + init  ekf.cpp:5-19
-                const double x0[6] = {px, py, yaw, 0, 0, 0};
-                xr = x0[r]; P = (r == c) ? 1.0 : 0.0; last_t = t; init = 1.0;
-            } else {
-                const double dtp = t - pt;
-                if (dtp > 0) {
-                    double dyaw = yaw - pyaw;
-                    if (dyaw > EKF_PI) dyaw -= 2 * EKF_PI;
-                    else if (dyaw < -EKF_PI) dyaw += 2 * EKF_PI;
-                    const double omega_m = dyaw / dtp;
-                    const double v_enc = (enc - penc) * metres_per_tick / dtp;
-                    // ---- predict  ekf.cpp:26-68 ----
-                    const double dt = t - last_t;
-                    if (init != 0.0 && dt > 0) {
-                        last_t = t;
-                        const double theta = ekf_rl(xr, 12), v = ekf_rl(xr, 18), bias = ekf_rl(xr, 30);
-                        const double omega_c = omega_m - bias;
-                        double theta_new = theta + omega_c * dt;
-                        if (theta_new > EKF_PI) theta_new -= 2 * EKF_PI;
-                        else if (theta_new < -EKF_PI) theta_new += 2 * EKF_PI;
-                        double ct, st;
-                        ekf_sincos(theta, &st, &ct);
-                        if (r == 0) xr = xr + v * ct * dt;
-                        else if (r == 1) xr = xr + v * st * dt;
-                        else if (r == 2) xr = theta_new;
-                        else if (r == 4) xr = omega_c;
-                        const double j02 = -v * st * dt, j03 = ct * dt, j12 = v * ct * dt, j13 = st * dt, j25 = -dt;
-                        const double p2 = __shfl(P, 12 + c), p3 = __shfl(P, 18 + c), p5 = __shfl(P, 30 + c);
-                        double JP;
-                        if (r == 0) JP = (P + j02 * p2) + j03 * p3;
-                        else if (r == 1) JP = (P + j12 * p2) + j13 * p3;
-                        else if (r == 2) JP = P + j25 * p5;
-                        else if (r == 4) JP = -1.0 * p5;
-                        else JP = P;
-                        const double r2 = __shfl(JP, 6 * r + 2), r3 = __shfl(JP, 6 * r + 3), r5 = __shfl(JP, 6 * r + 5);
-                        double M;
-                        if (c == 0) M = (JP + r2 * j02) + r3 * j03;
-                        else if (c == 1) M = (JP + r2 * j12) + r3 * j13;
-                        else if (c == 2) M = JP + r5 * j25;
-                        else if (c == 4) M = r5 * -1.0;
-                        else M = JP;
-                        P = M + qdiag;
-                    }
-                    // ---- update  ekf.cpp:70-92 ----
-                    if (init != 0.0) {
-                        const double y0 = v_enc - ekf_rl(xr, 18), y1 = omega_m - ekf_rl(xr, 24);
-                        const double s00 = ekf_rl(P, 21) + R0, s01 = ekf_rl(P, 22);
-                        const double s10 = ekf_rl(P, 27), s11 = ekf_rl(P, 28) + R1;
-                        const double det = s00 * s11 - s01 * s10;
-                        const double i00 = s11 / det, i01 = -s01 / det, i10 = -s10 / det, i11 = s00 / det;
-                        const double pr3 = __shfl(P, 6 * r + 3), pr4 = __shfl(P, 6 * r + 4);
-                        const double K0 = pr3 * i00 + pr4 * i10, K1 = pr3 * i01 + pr4 * i11;
-                        xr = xr + (K0 * y0 + K1 * y1);
-                        const double p3c = __shfl(P, 18 + c), p4c = __shfl(P, 24 + c);
-                        double Pn;
-                        if (r < 3) Pn = (P + (-K0) * p3c) + (-K1) * p4c;
-                        else if (r == 3) Pn = (1.0 - K0) * p3c + (-K1) * p4c;
-                        else if (r == 4) Pn = (-K0) * p3c + (1.0 - K1) * p4c;
-                        else Pn = ((-K0) * p3c + (-K1) * p4c) + P;
-                        P = Pn;
-                    }
+            const int kind = __builtin_amdgcn_readlane(kind_l, j);
+            if (kind == 0) {                                          // EKF::EKF + init  ekf.cpp:5-19
+                const double x0[6] = {ekf_rl(px_l, j), ekf_rl(py_l, j), ekf_rl(yaw_l, j), 0, 0, 0};
+                xr = x0[r]; P = (r == c) ? 1.0 : 0.0; last_t = ekf_rl(t_l, j); init = 1.0;
+            } else if (kind == 1 && init != 0.0) {
+                const double t = ekf_rl(t_l, j), omega_m = ekf_rl(om_l, j), v_enc = ekf_rl(ve_l, j);
+                // ---- predict  ekf.cpp:26-68 ----
+                const double dt = t - last_t;
+                if (dt > 0) {
+                    last_t = t;
+                    const double theta = ekf_rl(xr, 12), v = ekf_rl(xr, 18), bias = ekf_rl(xr, 30);
+                    const double omega_c = omega_m - bias;
+                    double theta_new = theta + omega_c * dt;
+                    if (theta_new > EKF_PI) theta_new -= 2 * EKF_PI;
+                    else if (theta_new < -EKF_PI) theta_new += 2 * EKF_PI;
+                    double ct, st;
+                    ekf_sincos(theta, &st, &ct);
+                    const double vct = v * ct, vst = v * st;
+                    const double j02 = -v * st * dt, j03 = ct * dt, j12 = vct * dt, j13 = st * dt, j25 = -dt;
+                    if (r == 0) xr = xr + vct * dt;
+                    else if (r == 1) xr = xr + vst * dt;
+                    else if (r == 2) xr = theta_new;
+                    else if (r == 4) xr = omega_c;
+                    // J P: (base + k1 * P[ra][c]) + k2 * P[3][c]
+                    const double k1 = (r == 0) ? j02 : (r == 1) ? j12 : (r == 2) ? j25 : (r == 4) ? -1.0 : 0.0;
+                    const double k2 = (r == 0) ? j03 : (r == 1) ? j13 : 0.0;
+                    const double JP = (((r == 4) ? 0.0 : P) + k1 * ekf_perm(P, col_a)) + k2 * ekf_perm(P, col_b);
+                    // (J P) J^T: (base + JP[r][ca] * k1') + JP[r][3] * k2'
+                    const double h1 = (c == 0) ? j02 : (c == 1) ? j12 : (c == 2) ? j25 : (c == 4) ? -1.0 : 0.0;
+                    const double h2 = (c == 0) ? j03 : (c == 1) ? j13 : 0.0;
+                    const double M = (((c == 4) ? 0.0 : JP) + ekf_perm(JP, row_a) * h1) + ekf_perm(JP, row_b) * h2;
+                    P = M + qdiag;
                 }
+                // ---- update  ekf.cpp:70-92 ----
+                const double pr3 = ekf_perm(P, row_3), pr4 = ekf_perm(P, row_4);
+                const double p3c = ekf_perm(P, col_3), p4c = ekf_perm(P, col_4);
+                const double y0 = v_enc - ekf_rl(xr, 18), y1 = omega_m - ekf_rl(xr, 24);
+                const double s00 = ekf_rl(P, 21) + R0, s01 = ekf_rl(P, 22);
+                const double s10 = ekf_rl(P, 27), s11 = ekf_rl(P, 28) + R1;
+                const double det = s00 * s11 - s01 * s10;
+                const double invdet = 1.0 / det;
+                const double i00 = s11 * invdet, i01 = -s01 * invdet, i10 = -s10 * invdet, i11 = s00 * invdet;
+                const double K0 = pr3 * i00 + pr4 * i10, K1 = pr3 * i01 + pr4 * i11;
+                xr = xr + (K0 * y0 + K1 * y1);
+                const double A = (r == 3) ? 1.0 - K0 : -K0, B = (r == 4) ? 1.0 - K1 : -K1;
+                const double tt = (((r < 3) ? P : 0.0) + A * p3c) + B * p4c;
+                P = (r == 5) ? tt + P : tt;
             }
-            pt = t; pyaw = yaw; penc = enc; seen = 1.0;
         }
     }
     if (lane < 36) {

@@ -205,7 +205,7 @@ extern "C" int qs_create(const qs_config *cfg, qs_ctx **out)
         double nbd = ceil(extent / cell);
         if (!(nbd >= 1)) nbd = 1;
         if (nbd > QS_MAX_BUCKETS_1D) nbd = QS_MAX_BUCKETS_1D;
-        c->bg = QsBucketGeom{cfg->ox - margin, cfg->oy - margin, cell, (int)nbd, (int)nbd};
+        c->bg = QsBucketGeom{cfg->ox - margin, cfg->oy - margin, cell, 1.0 / cell, (int)nbd, (int)nbd};
         c->dir_entries = (size_t)QS_NTYPES * (size_t)c->bg.nbx * (size_t)c->bg.nby;
     }
     const int nb = cfg->max_agent + 1;

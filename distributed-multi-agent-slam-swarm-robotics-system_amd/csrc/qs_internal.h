@@ -40,7 +40,7 @@ __host__ __device__ inline double qs_double_from_ord(unsigned long long k)
 #define QS_MAX_BUCKETS_1D 2048
 struct alignas(64) QsLmNode { long long idx[8]; double x[8]; double y[8]; };   // idx 0x7f7f.. = empty slot
 struct QsDirEntry { unsigned int head, tail, tail_cnt, pad; };                  // head 0 = empty bucket
-struct QsBucketGeom { double bx0, by0, cell; int nbx, nby; };
+struct QsBucketGeom { double bx0, by0, cell, inv_cell; int nbx, nby; };
 
 struct QsGraphDev {
     long long n_nodes;     // len(self.nodes)

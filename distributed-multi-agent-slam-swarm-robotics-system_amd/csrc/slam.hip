@@ -165,9 +165,12 @@ __device__ inline void lds_barrier()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-__device__ inline long long bucket_coord(double v, double b0, double cell)
+// Bucket index along one axis.  Only consistency between insert and query matters (not the
+// reference's arithmetic): the edge exceeds the closure radius by 1e-9 relative, so two points
+// closer than the radius are never two buckets apart whatever the rounding of this product.
+__device__ inline long long bucket_coord(double v, double b0, double inv_cell)
 {
-    const double f = floor((v - b0) / cell);
+    const double f = floor((v - b0) * inv_cell);
     return (fabs(f) < 1.0e9) ? (long long)f : -1000000000ll;
 }
 
@@ -185,14 +188,12 @@ __device__ inline void bucket_prepare(double x, double y, int type, const QsBuck
 {
     kb = -1; nbmask = 0;
     if (type < 1 || type > QS_NTYPES) return;
-    const long long cx = bucket_coord(x, bg.bx0, bg.cell), cy = bucket_coord(y, bg.by0, bg.cell);
+    const long long cx = bucket_coord(x, bg.bx0, bg.inv_cell), cy = bucket_coord(y, bg.by0, bg.inv_cell);
     if (cx < -1 || cx > bg.nbx || cy < -1 || cy > bg.nby) return;
     kb = (type - 1) * dir_slab + cy * bg.nbx + cx;
-    #pragma unroll
-    for (int q = 0; q < 9; q++) {
-        const long long nx = cx + (q % 3) - 1, ny = cy + (q / 3) - 1;
-        if (nx >= 0 && nx < bg.nbx && ny >= 0 && ny < bg.nby) nbmask |= 1u << q;
-    }
+    // bit q = 3 * (dy + 1) + (dx + 1) is set when neighbour (cx + dx, cy + dy) exists
+    const unsigned int xm = (cx >= 1 ? 1u : 0u) | ((cx >= 0 && cx < bg.nbx) ? 2u : 0u) | (cx + 1 < bg.nbx ? 4u : 0u);
+    nbmask = (cy >= 1 ? xm : 0u) | ((cy >= 0 && cy < bg.nby) ? xm << 3 : 0u) | (cy + 1 < bg.nby ? xm << 6 : 0u);
 }
 
 __global__ void __launch_bounds__(CH_THREADS)
@@ -233,7 +234,7 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
     long long n_lms = G.n_lms, n_cls = G.n_cls, n_misc = G.n_misc;     // authoritative in wave 0
     unsigned int pool = G.nodes_used;
     const long long dir_slab = (long long)bg.nbx * bg.nby;
-    unsigned long long st_windows = 0, st_rounds = 0, st_iters = 0, st_misc = 0;
+    unsigned long long st_windows = 0, st_rounds = 0, st_iters = 0, st_misc = 0, st_a = 0, st_b = 0, st_c = 0;
     const unsigned long long t0_cyc = __builtin_amdgcn_s_memtime(), t0_real = __builtin_amdgcn_s_memrealtime();
 
     // registers of wave 0 that live across the phases of one window
@@ -254,6 +255,7 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
 
     for (unsigned int e = e0; e < e1;) {
         // ---- phase A (wave 0): the next events whose node index is < first + win ---------------------
+        const unsigned long long ta0 = __builtin_amdgcn_s_memtime();
         if (wave == 0) {
             const bool have = lane < 32 && e + lane < e1;
             idx = LL_MAX; a = 0; type = 0; px = 0; py = 0;
@@ -275,6 +277,7 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
             st_windows++;
         }
         lds_barrier();
+        const unsigned long long tb0 = __builtin_amdgcn_s_memtime();
         const int k = s_k;
         const unsigned long long emask = s_emask;
         // the last wave fetches the next window's events while the queries run
@@ -372,6 +375,7 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
         }
         if (fetcher) { n_idx[lane] = f_idx; n_a[lane] = f_a; n_type[lane] = f_type; n_px[lane] = f_px; n_py[lane] = f_py; }
         lds_barrier();
+        const unsigned long long tc0 = __builtin_amdgcn_s_memtime();
 
         // ---- phase C (wave 0): commit, in node order ------------------------------------------------------
         if (wave == 0) {
@@ -466,6 +470,7 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
         e += k;
         // this window's stores (landmarks, directory) are ordered before the next window's loads
         __syncthreads();
+        st_a += tb0 - ta0; st_b += tc0 - tb0; st_c += __builtin_amdgcn_s_memtime() - tc0;
     }
 
     for (int t = tid; t < nb; t += CH_THREADS) {
@@ -484,6 +489,7 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
         atomicAdd(&counters[QS_CNT_CLOSURES], (unsigned long long)(n_cls - G.n_cls));
         atomicAdd(&counters[QS_CNT_LANDMARKS], (unsigned long long)(n_lms - G.n_lms));
         atomicAdd(&counters[QS_CNT_SLAM_WINDOWS], st_windows);
+        atomicAdd(&counters[QS_CNT_SLAM_CYC_A], st_a); atomicAdd(&counters[QS_CNT_SLAM_CYC_B], st_b); atomicAdd(&counters[QS_CNT_SLAM_CYC_C], st_c);
         atomicAdd(&counters[QS_CNT_SLAM_CYCLES], __builtin_amdgcn_s_memtime() - t0_cyc);
         atomicAdd(&counters[QS_CNT_SLAM_REALTIME], __builtin_amdgcn_s_memrealtime() - t0_real);
         graphs[g].n_nodes = G.n_nodes + sb.acc_total[g];

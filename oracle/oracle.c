@@ -481,7 +481,8 @@ void qso_ekf_update(double *f, double z_v, double z_omega)  /* ekf.cpp:70-92 */
     double s00 = P[3 * 6 + 3] + EKF_R[0], s01 = P[3 * 6 + 4];
     double s10 = P[4 * 6 + 3],            s11 = P[4 * 6 + 4] + EKF_R[1];
     double det = s00 * s11 - s01 * s10;
-    double i00 = s11 / det, i01 = -s01 / det, i10 = -s10 / det, i11 = s00 / det;
+    double invdet = 1.0 / det;   /* 2x2 inverse as adjugate * (1/det), as Eigen's fixed-size path does */
+    double i00 = s11 * invdet, i01 = -s01 * invdet, i10 = -s10 * invdet, i11 = s00 * invdet;
     double K[12];
     for (int r = 0; r < 6; r++) {
         double p3 = P[6 * r + 3], p4 = P[6 * r + 4];
@@ -505,8 +506,8 @@ void qso_ekf_update(double *f, double z_v, double z_omega)  /* ekf.cpp:70-92 */
 /* Build-defined wiring of the EKF to the telemetry stream (modelled on
  * esp32_firmware/src/main.cpp:176-188): per accepted packet of a bot, in arrival order,
  *   first packet: init(t, [x, y, yaw, 0, 0, 0]);
- *   later: dt = t - t_prev; if dt > 0: omega_m = wrap(yaw - yaw_prev)/dt,
- *          v_enc = (enc - enc_prev) * metres_per_tick / dt; predict(omega_m, t); update(v_enc, omega_m)
+ *   later: dt = t - t_prev; if dt > 0: inv_dt = 1/dt, omega_m = wrap(yaw - yaw_prev) * inv_dt,
+ *          v_enc = (enc - enc_prev) * metres_per_tick * inv_dt; predict(omega_m, t); update(v_enc, omega_m)
  * One step of that wiring, for one bot, given already-decoded fields.  prev = {t, yaw, enc, seen}. */
 void qso_ekf_packet(double *f, double *prev, double t, double x, double y, double yaw,
                     double enc, double metres_per_tick)
@@ -520,8 +521,9 @@ void qso_ekf_packet(double *f, double *prev, double t, double x, double y, doubl
             double dyaw = yaw - prev[1];
             if (dyaw > M_PI) dyaw -= 2 * M_PI;
             else if (dyaw < -M_PI) dyaw += 2 * M_PI;
-            double omega_m = dyaw / dt;
-            double v_enc = (enc - prev[2]) * metres_per_tick / dt;
+            double inv_dt = 1.0 / dt;
+            double omega_m = dyaw * inv_dt;
+            double v_enc = (enc - prev[2]) * metres_per_tick * inv_dt;
             qso_ekf_predict(f, omega_m, t);
             qso_ekf_update(f, v_enc, omega_m);
         }
