@@ -28,13 +28,24 @@ def grid_tensors(mapper, device):
     return stamps, counts
 
 
-def allreduce_grids(mapper, device, group=None, counts=True):
-    """Fuse every rank's grid into the global map, in place on all ranks."""
+def allreduce_tensors(stamps, counts=None, group=None):
+    """The fuse rule on plain tensors (any backend): latest stamp wins, counters add."""
     import torch.distributed as dist
-    stamps, cnt = grid_tensors(mapper, device)
     dist.all_reduce(stamps, op=dist.ReduceOp.MAX, group=group)
-    if counts and cnt is not None:
-        dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=group)
+    if counts is not None:
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
+
+
+def allreduce_grids(mapper, device, group=None, counts=True):
+    """Fuse every rank's grid into the global map, in place on all ranks (RCCL over xGMI)."""
+    stamps, cnt = grid_tensors(mapper, device)
+    allreduce_tensors(stamps, cnt if counts else None, group)
+
+
+def tri_state_from_stamps(stamps):
+    """Host decode of a stamp grid to OccupancyGrid values (-1 / 0 / 100), for checks."""
+    s = np.asarray(stamps).astype(np.int64)
+    return np.where(s == 0, -1, np.where(s & 1, 100, 0)).astype(np.int8)
 
 
 def shard_of_bot(bot_index, bots_per_gpu):

@@ -49,6 +49,9 @@ typedef struct {
     int size; double res, ox, oy;          /* OccupancyGrid ctor :113-119 */
     int8_t *grid;                           /* np.full((size,size), -1, int8), [gy][gx] */
     int32_t *hits, *misses;                 /* build extension: per-cell write counts */
+    uint32_t *stamps;                       /* build extension: (ordinal << 1) | occ of the latest write,
+                                               ordinal = 4 * arrival index + sensor + 1 (0 = never written) */
+    uint64_t cur_seq; int cur_sensor; uint64_t seq_next, seq_stride;
     int max_agent;                          /* accept agent_id 1..max_agent (reference: 2, :842) */
     int bots_per_graph;                     /* bots sharing one PoseGraphSLAM (reference: all) */
     int n_graphs;
@@ -94,6 +97,10 @@ static void update_ray(mapper_t *m, double rx, double ry, double hx, double hy, 
             if (in_bounds(m, x0, y0)) {
                 size_t c = (size_t)y0 * m->size + x0;
                 m->grid[c] = last ? CELL_OCCUPIED : CELL_FREE;
+                {
+                    uint32_t key = (uint32_t)(((4 * m->cur_seq + (uint64_t)m->cur_sensor + 1) << 1) | (last ? 1u : 0u));
+                    if (key > m->stamps[c]) m->stamps[c] = key;
+                }
                 if (last) m->hits[c]++; else m->misses[c]++;
                 m->n_cells_written++;
             }
@@ -162,6 +169,8 @@ mapper_t *qso_create(int size, double res, double ox, double oy, double separati
     m->grid = malloc(cells); memset(m->grid, CELL_UNKNOWN, cells);
     m->hits = calloc(cells, sizeof(int32_t));
     m->misses = calloc(cells, sizeof(int32_t));
+    m->stamps = calloc(cells, sizeof(uint32_t));
+    m->seq_stride = 1;
     m->graphs = calloc(m->n_graphs, sizeof(graph_t));
     int nb = m->max_agent + 1;
     m->offset_x = calloc(nb, sizeof(double));
@@ -179,7 +188,7 @@ void qso_destroy(mapper_t *m)
 {
     if (!m) return;
     for (int g = 0; g < m->n_graphs; g++) { free(m->graphs[g].lms); free(m->graphs[g].cls); }
-    free(m->grid); free(m->hits); free(m->misses); free(m->graphs); free(m->offset_x);
+    free(m->grid); free(m->hits); free(m->misses); free(m->stamps); free(m->graphs); free(m->offset_x);
     free(m->drift); free(m->last_closure); free(m->zone); free(m->zone_n); free(m->pkt_count);
     free(m->ekf); free(m->ekf_prev);
     free(m->pose); free(m->pose_agent); free(m->pose_src); free(m->hit); free(m->hit_agent_sensor);
@@ -215,6 +224,7 @@ static float rd_f32(const uint8_t *p) { float f; memcpy(&f, p, 4); return f; }
 int qso_feed(mapper_t *m, const uint8_t *d, int len)
 {
     long src = m->n_datagrams++;
+    m->cur_seq = m->seq_next; m->seq_next += m->seq_stride;   /* arrival index of this datagram */
     int lm = 0;
     if (len == PACKET_SIZE) lm = d[41];                 /* :828-831 */
     else if (len != PACKET_SIZE_V1) return 0;            /* :832-838 */
@@ -244,6 +254,7 @@ int qso_feed(mapper_t *m, const uint8_t *d, int len)
     m->pose[3 * m->n_pose] = rx; m->pose[3 * m->n_pose + 1] = ry; m->pose[3 * m->n_pose + 2] = ryaw;
     m->pose_agent[m->n_pose] = agent; m->pose_src[m->n_pose] = src; m->n_pose++;
     for (int s = 0; s < 4; s++) {                        /* :886-903 */
+        m->cur_sensor = s;
         double a = ryaw + SENSOR_ANGLES_RAD[s];
         double dd = dist[s];
         int valid = (MIN_DIST_M < dd) && (dd <= MAX_DIST_M);
@@ -326,6 +337,9 @@ long qso_bresenham(long x0, long y0, long x1, long y1, int64_t *out, long cap)
 
 /* ---- read-back ----------------------------------------------------------------------- */
 const int8_t *qso_grid(const mapper_t *m) { return m->grid; }
+const uint32_t *qso_stamps(const mapper_t *m) { return m->stamps; }
+/* arrival indices of the following datagrams: seq0, seq0 + stride, ... (sharded streams) */
+void qso_set_sequence(mapper_t *m, uint64_t seq0, uint64_t stride) { m->seq_next = seq0; m->seq_stride = stride ? stride : 1; }
 const int32_t *qso_hits(const mapper_t *m) { return m->hits; }
 const int32_t *qso_misses(const mapper_t *m) { return m->misses; }
 long qso_n_nodes(const mapper_t *m, int g) { return m->graphs[g].n_nodes; }

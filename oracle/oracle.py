@@ -48,7 +48,8 @@ def lib():
         L.qso_world_to_grid.argtypes = [vp, vp, i64, i32, vp]
         L.qso_bresenham.restype = i64
         L.qso_bresenham.argtypes = [i64, i64, i64, i64, vp, i64]
-        for name in ("qso_grid", "qso_hits", "qso_misses", "qso_poses", "qso_pose_agents",
+        L.qso_set_sequence.argtypes = [vp, C.c_uint64, C.c_uint64]
+        for name in ("qso_grid", "qso_stamps", "qso_hits", "qso_misses", "qso_poses", "qso_pose_agents",
                      "qso_hit_points", "qso_hit_agent_sensor"):
             getattr(L, name).restype = vp
             getattr(L, name).argtypes = [vp]
@@ -146,6 +147,13 @@ class OracleMapper:
     @property
     def grid(self):
         return _view(lib().qso_grid(self._h), (self.size, self.size), np.int8)
+
+    @property
+    def stamps(self):
+        return _view(lib().qso_stamps(self._h), (self.size, self.size), np.uint32)
+
+    def set_sequence(self, seq0, stride=1):
+        lib().qso_set_sequence(self._h, seq0, stride)
 
     @property
     def hits(self):
