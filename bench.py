@@ -63,6 +63,30 @@ def cpu_baseline(stream, grid, sample, ekf, times):
                       f"host has {os.cpu_count()} logical CPUs"}
 
 
+RAYCAST_KERNELS = ("qs_rays_kernel", "qs_table_scan_kernel", "qs_tile_scan_kernel", "qs_scatter_kernel",
+                   "qs_raster_kernel")
+
+
+def pmc_traffic_bytes(batch, counts):
+    """HBM bytes per launch of the raycast stage from the committed rocprofv3 PMC summaries
+    (profiles/r01, separate --pmc passes of this same command at 2^20 packets, counters on):
+    FETCH_SIZE is doubled (gfx950 reports half of a wide coalesced read, MI355X_MICROARCH.md
+    section HBM), WRITE_SIZE taken as is; both are in KiB.  None when the run differs from the
+    profiled configuration."""
+    if batch != (1 << 20) or not counts:
+        return None
+    total = 0.0
+    for fname, scale in (("bench_B1M_pmc_FETCH_SIZE.csv", 2.0), ("bench_B1M_pmc_WRITE_SIZE.csv", 1.0)):
+        path = os.path.join(ROOT, "profiles", "r01", fname)
+        if not os.path.exists(path):
+            return None
+        for line in open(path).read().splitlines()[1:]:
+            f = line.split(",")
+            if any(k in f[0] for k in RAYCAST_KERNELS):
+                total += float(f[-1]) * 1024.0 * scale
+    return total
+
+
 def main():
     args = parse()
     import torch
@@ -143,7 +167,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64 pose/trig + u32 stamps",
+            "dtype": "f64",
             "data": "synthetic: reference generator's 2-bot session cycled",
             "config": {"workload": f"configs[1]: 2-bot stream, {G}x{G} grid, res 0.05, {B} packets/step/GPU, "
                                    f"fresh session per step, decode+loop-closure+raycast"
@@ -152,9 +176,12 @@ def main():
                        "raycast_mode": args.raycast_mode, "sharding": f"by agent, {world} x 2 bots"},
             "stages_ms_per_step": {k: (v[0] / max(v[1], 1)) for k, v in stages.items() if v[1]},
             "counters_per_step": cnt,
-            "roofline": {"bound": "hbm", "kernel": "raycast (K1)", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "roofline": {"bound": "hbm", "kernel": "K1 raycast stage (qs_rays + 2 scans + qs_scatter + qs_raster)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": pmc_traffic_bytes(B, not args.no_counts),
                          "algorithmic_bytes_per_launch": alg_bytes,
+                         "algorithmic_bytes_rule": "42 B/packet + in-bounds cell writes x (8 B stamp RMW + 8 B counter RMW)",
                          "avg_launch_ms": ray_avg_s * 1e3},
         }
         if not args.no_cpu_baseline:

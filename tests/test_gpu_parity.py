@@ -295,3 +295,88 @@ def test_map_merger_ops_match_oracle(pkg):
         ogrid, oorigin = orc.rasterise(merged, 0.05)
         assert grid.shape == ogrid.shape and (grid == ogrid).all() and (origin == oorigin).all()
         assert m.rasterise(np.zeros((0, 2)), 0.05) == (None, None)
+
+
+def _replay(pkg):
+    import importlib
+    return importlib.import_module(pkg.__name__ + ".replay")
+
+
+def test_full_size_properties_4096(pkg):
+    """BASELINE configs[1] at full grid size (4096^2) and a 2^18-packet stream: properties that do
+    not need the (quadratic) oracle over the whole stream -- the two raycast schedules agree bit for
+    bit, ragged batching is invisible, counters are consistent -- plus the oracle on a prefix."""
+    replay = _replay(pkg)
+    session, _ = replay.telemetry_csv_to_packets()
+    B = 1 << 18
+    stream = replay.cycle_stream(session, B)
+    kw = dict(size=4096, resolution=0.05, origin_x=-102.4, origin_y=-102.4)
+    with pkg.QuasarMapper(raycast_mode=2, **kw) as t, pkg.QuasarMapper(raycast_mode=1, **kw) as d:
+        t.ingest_array(stream); d.ingest_array(stream)
+        gt, gd = t.grid_i8(), d.grid_i8()
+        assert (gt == gd).all()
+        (ht, mt), (hd, md) = t.counts(), d.counts()
+        assert (ht == hd).all() and (mt == md).all()
+        c = t.counters()
+        assert int(ht.sum()) + int(mt.sum()) == c["cells"] and c["rays"] == 4 * B and c["accepted"] == B
+        assert ((ht + mt > 0) == (gt != -1)).all()
+        assert t.slam_sizes(0) == d.slam_sizes(0)
+        assert (t.closures(0)[0] == d.closures(0)[0]).all()
+        # ragged batches
+        t.reset()
+        pos = 0
+        for step in (1, 70000, 33, 100000, 4096, B):
+            t.ingest_array(stream[pos:pos + step]); pos += step
+            if pos >= B:
+                break
+        assert (t.grid_i8() == gt).all() and (t.counts()[0] == ht).all()
+        assert (t.closures(0)[0] == d.closures(0)[0]).all()
+    # oracle on a prefix (its landmark scan is O(L) per event)
+    n = 40000
+    o = orc.OracleMapper(4096, 0.05, -102.4, -102.4, 0.0)
+    o.feed_stream(stream[:n])
+    with pkg.QuasarMapper(**kw) as m:
+        m.ingest_array(stream[:n])
+        assert (m.grid_i8() == o.grid).all()
+        h, mi = m.counts()
+        assert (h == o.hits).all() and (mi == o.misses).all()
+        idx, corr = m.closures(0); oi, oc = o.closures(0)
+        assert (idx == oi).all() and np.abs(corr - oc).max() < FLOAT_TOL
+        for b in (1, 2):
+            assert np.abs(m.drift(b) - o.drift(b)).max() < FLOAT_TOL
+            assert np.abs(np.array(m.zone(b)) - o.zone(b)).max() < FLOAT_TOL
+
+
+def test_64_bots_32_graphs_vs_oracle(pkg):
+    """BASELINE configs[2] shape: 64 bots on one GPU, one pose graph per 2 bots (the reference's
+    deployment unit), 4096^2 grid."""
+    replay = _replay(pkg)
+    session, _ = replay.telemetry_csv_to_packets()
+    n = 64 * 700
+    stream = replay.multi_bot_stream(session, 64, n)
+    o = orc.OracleMapper(4096, 0.05, -102.4, -102.4, 0.0, max_agent=64, bots_per_graph=2)
+    assert o.feed_stream(stream) == n
+    with pkg.QuasarMapper(4096, 0.05, -102.4, -102.4, max_agent=64, bots_per_graph=2) as m:
+        m.ingest_array(stream[:20000]); m.ingest_array(stream[20000:])
+        assert (m.grid_i8() == o.grid).all()
+        h, mi = m.counts()
+        assert (h == o.hits).all() and (mi == o.misses).all()
+        total = 0
+        for gr in range(32):
+            idx, corr = m.closures(gr); oi, oc = o.closures(gr)
+            assert (idx == oi).all(), gr
+            if len(oi):
+                assert np.abs(corr - oc).max() < FLOAT_TOL
+            total += len(oi)
+            assert m.slam_sizes(gr)[0] == o.n_nodes(gr)
+        assert total > 100
+        for b in range(1, 65):
+            assert np.abs(m.drift(b) - o.drift(b)).max() < FLOAT_TOL
+            assert np.abs(np.array(m.zone(b)) - o.zone(b)).max() < FLOAT_TOL
+    # all 64 bots in ONE pose graph (the reference's own semantics, cross-bot matches allowed)
+    o1 = orc.OracleMapper(4096, 0.05, -102.4, -102.4, 0.0, max_agent=64)
+    o1.feed_stream(stream[:16000])
+    with pkg.QuasarMapper(4096, 0.05, -102.4, -102.4, max_agent=64) as m:
+        m.ingest_array(stream[:16000])
+        assert (m.grid_i8() == o1.grid).all()
+        assert (m.closures(0)[0] == o1.closures(0)[0]).all()
