@@ -380,3 +380,32 @@ def test_64_bots_32_graphs_vs_oracle(pkg):
         m.ingest_array(stream[:16000])
         assert (m.grid_i8() == o1.grid).all()
         assert (m.closures(0)[0] == o1.closures(0)[0]).all()
+
+
+def test_device_buffer_aliasing_and_nccl_allreduce_single_rank(pkg):
+    """The N>1 plumbing on one GPU: torch aliases the library's stamp / counter buffers through
+    __cuda_array_interface__, and the RCCL all-reduce (world_size 1) runs on them in place."""
+    import importlib
+    import torch
+    import torch.distributed as dist
+    distmod = importlib.import_module(pkg.__name__ + ".dist")
+    g = load("session_512")
+    dev = torch.device("cuda", 0)
+    with make_mapper(pkg, g) as m:
+        m.ingest_array(g["datagrams"], g["lengths"])
+        stamps, counts = distmod.grid_tensors(m, dev)
+        assert stamps.dtype == torch.int32 and tuple(stamps.shape) == (512, 512) and tuple(counts.shape) == (512, 512, 2)
+        tri = distmod.tri_state_from_stamps(stamps.cpu().numpy())
+        assert (tri == m.grid_i8()).all()
+        hits, misses = m.counts()
+        assert (counts[..., 1].cpu().numpy() == hits).all() and (counts[..., 0].cpu().numpy() == misses).all()
+        assert int(stamps.max()) < 2 ** 31 and int(stamps.min()) >= 0
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29577")
+        dist.init_process_group("nccl", rank=0, world_size=1)
+        try:
+            distmod.allreduce_grids(m, dev)
+            torch.cuda.synchronize()
+        finally:
+            dist.destroy_process_group()
+        assert hashlib.sha256(m.grid_i8().tobytes()).digest() == g["grid_sha256"].tobytes()
+        assert (m.counts()[0] == hits).all()
