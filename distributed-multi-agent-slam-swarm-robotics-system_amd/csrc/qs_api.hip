@@ -266,7 +266,7 @@ extern "C" int qs_destroy(qs_ctx *c)
     hipFree(c->d_stamps); hipFree(c->d_counts); hipFree(c->d_offset); hipFree(c->d_drift);
     hipFree(c->d_last_closure); hipFree(c->d_zone); hipFree(c->d_counters); hipFree(c->d_graph_batch);
     hipFree(c->d_ekf); hipFree(c->d_ekf_prev); hipFree(c->d_graphs); hipFree(c->d_pkts); hipFree(c->d_lens);
-    hipFree(c->d_time); hipFree(c->d_bin_ws);
+    hipFree(c->d_time); hipFree(c->d_bin_ws); hipFree(c->d_frontier_ws);
     for (auto &p : c->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (auto e : c->ev_pool) hipEventDestroy(e);
     if (c->ekf_stream) { hipStreamSynchronize(c->ekf_stream); hipStreamDestroy(c->ekf_stream); }
@@ -848,6 +848,58 @@ extern "C" int qs_rasterise(qs_ctx *c, const double *xy, size_t n, double res, i
     if (e != hipSuccess) return qs_fail(c, QS_E_HIP, "qs_rasterise", e);
     return rc;
 }
+
+// ---- frontiers ------------------------------------------------------------------------------------
+static int frontier_run(qs_ctx *c, int mode, int32_t min_cluster, int32_t *xy, int64_t *stats5, size_t cap, size_t *n_out)
+{
+    ARGCHK(c, c != nullptr && n_out != nullptr);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->d_frontier_ws) HIPCHK(c, hipMalloc(&c->d_frontier_ws, qs_frontier_workspace_bytes(c)));
+    void *ws = c->d_frontier_ws;
+    HIPCHK(c, qs_launch_frontier_label(c, ws, mode == 1));
+    HIPCHK(c, qs_launch_frontier_compact(c, ws, mode, 0, nullptr, nullptr, 0));
+    unsigned long long total = 0;
+    HIPCHK(c, hipMemcpyAsync(&total, qs_frontier_total_ptr(c, ws), sizeof total, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (mode == 0) {
+        *n_out = (size_t)total;
+        if (!xy || total == 0) return QS_OK;
+        int *d = nullptr;
+        HIPCHK(c, hipMalloc((void **)&d, 2 * (size_t)total * sizeof(int)));
+        hipError_t e = qs_launch_frontier_compact(c, ws, 0, 1, d, nullptr, (size_t)total);
+        const size_t m = total < cap ? (size_t)total : cap;
+        if (e == hipSuccess) e = hipMemcpyAsync(xy, d, 2 * m * sizeof(int), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        hipFree(d);
+        if (e != hipSuccess) return qs_fail(c, QS_E_HIP, "qs_frontier_cells", e);
+        return QS_OK;
+    }
+    // clusters: all components come back in first-cell order; the size filter keeps that order (:228-229)
+    std::vector<long long> all(5 * (size_t)total);
+    if (total) {
+        long long *d = nullptr;
+        HIPCHK(c, hipMalloc((void **)&d, 5 * (size_t)total * sizeof(long long)));
+        hipError_t e = qs_launch_frontier_compact(c, ws, 1, 1, nullptr, d, (size_t)total);
+        if (e == hipSuccess) e = hipMemcpyAsync(all.data(), d, all.size() * sizeof(long long), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        hipFree(d);
+        if (e != hipSuccess) return qs_fail(c, QS_E_HIP, "qs_frontier_clusters", e);
+    }
+    size_t k = 0;
+    for (size_t i = 0; i < (size_t)total; i++) {
+        if (all[5 * i] < min_cluster) continue;
+        if (stats5 && k < cap) memcpy(stats5 + 5 * k, &all[5 * i], 5 * sizeof(long long));
+        k++;
+    }
+    *n_out = k;
+    return QS_OK;
+}
+
+extern "C" int qs_frontier_cells(qs_ctx *c, int32_t *xy, size_t cap, size_t *n_out)
+{ return frontier_run(c, 0, 0, xy, nullptr, cap, n_out); }
+
+extern "C" int qs_frontier_clusters(qs_ctx *c, int32_t min_cluster, int64_t *stats5, size_t cap, size_t *n_out)
+{ return frontier_run(c, 1, min_cluster, nullptr, stats5, cap, n_out); }
 
 // ---- EKF --------------------------------------------------------------------------------------------
 extern "C" int qs_ekf_init(qs_ctx *c, int32_t bot, double t, const double x0[6])

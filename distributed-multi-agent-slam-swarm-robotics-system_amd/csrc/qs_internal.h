@@ -140,6 +140,7 @@ struct qs_ctx {
 
     // tile-binned raycast workspace
     void *d_bin_ws = nullptr; size_t bin_ws_bytes = 0;
+    void *d_frontier_ws = nullptr;               // frontier labelling workspace (allocated on first use)
 
     uint64_t next_seq = 0, epoch_base = 0, n_rebases = 0;
 
@@ -186,6 +187,11 @@ hipError_t qs_launch_grid_to_pcd(qs_ctx *c, const signed char *d_grid, int h, in
 hipError_t qs_launch_rasterise(qs_ctx *c, const double *d_xy, size_t n, double res, double minx,
                                double miny, int h, int w, signed char *d_grid);
 hipError_t qs_launch_bbox(qs_ctx *c, const double *d_xy, size_t n, unsigned long long *d_box4);
+// frontier.hip
+size_t qs_frontier_workspace_bytes(const qs_ctx *c);
+hipError_t qs_launch_frontier_label(qs_ctx *c, void *ws, bool with_clusters);
+hipError_t qs_launch_frontier_compact(qs_ctx *c, void *ws, int mode, int phase, int *d_xy, long long *d_stats, size_t cap);
+unsigned long long *qs_frontier_total_ptr(const qs_ctx *c, void *ws);
 // ekf.hip
 hipError_t qs_launch_ekf_ingest(qs_ctx *c, size_t n, const double *d_time, hipStream_t st);
 hipError_t qs_launch_ekf_step(qs_ctx *c, const int *d_bots, const double *d_omega, const double *d_t,

@@ -265,6 +265,36 @@ class QuasarMapper:
                   "qs_rasterise")
         return grid, origin
 
+    # -- frontiers: dual_bot_mapper.py:181-237, :948-956 ----------------------------------------
+    def frontier_cells(self):
+        """OccupancyGrid.get_frontiers() -> int32 [n, 2] (gx, gy), row-major order."""
+        n = C.c_size_t()
+        self._chk(self._L.qs_frontier_cells(self._h, None, 0, C.byref(n)), "qs_frontier_cells")
+        xy = np.zeros((n.value, 2), dtype=np.int32)
+        if n.value:
+            self._chk(self._L.qs_frontier_cells(self._h, _ptr(xy), n.value, C.byref(n)), "qs_frontier_cells")
+        return xy
+
+    def frontier_clusters(self, min_cluster=3):
+        """cluster_frontiers() as int64 [k, 5]: size, first_gx, first_gy, sum_gx, sum_gy, in the
+        reference's cluster order."""
+        n = C.c_size_t()
+        self._chk(self._L.qs_frontier_clusters(self._h, min_cluster, None, 0, C.byref(n)), "qs_frontier_clusters")
+        st = np.zeros((n.value, 5), dtype=np.int64)
+        if n.value:
+            self._chk(self._L.qs_frontier_clusters(self._h, min_cluster, _ptr(st), n.value, C.byref(n)),
+                      "qs_frontier_clusters")
+        return st
+
+    def frontier_centroids(self, min_cluster=3):
+        """[cluster_centroid_world(c) for c in clusters] (:955): mean cell index by true division,
+        then grid_to_world (:127-131, cell centre)."""
+        out = []
+        for size, _, _, sx, sy in self.frontier_clusters(min_cluster).tolist():
+            ax, ay = sx / size, sy / size
+            out.append((self.ox + (ax + 0.5) * self.res, self.oy + (ay + 0.5) * self.res))
+        return out
+
     # -- EKF --------------------------------------------------------------------------------------
     def ekf_init(self, bot, t, x0):
         x0 = np.ascontiguousarray(x0, dtype=np.float64)
@@ -340,6 +370,12 @@ class OccupancyGrid:
 
     def update_rays(self, robot_x, robot_y, hit_x, hit_y, hit_valid):
         self._m.update_rays(robot_x, robot_y, hit_x, hit_y, hit_valid)
+
+    def get_frontiers(self):                              # :181-196
+        return [tuple(c) for c in self._m.frontier_cells().tolist()]
+
+    def frontier_centroids(self, min_cluster=P.FRONTIER_MIN_CLUSTER):    # :951-956
+        return self._m.frontier_centroids(min_cluster)
 
 
 class PoseGraphSLAM:

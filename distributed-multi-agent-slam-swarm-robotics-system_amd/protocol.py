@@ -39,6 +39,9 @@ CELL_UNKNOWN, CELL_FREE, CELL_OCCUPIED = -1, 0, 100
 CLOSURE_RADIUS = 0.60
 MIN_POSES_BETWEEN = 30
 CLOSURE_CORRECTION = 0.5
+FRONTIER_MIN_CLUSTER = 3
+FRONTIER_SEPARATION = 1.0
+TARGET_INTERVAL = 3.0
 
 # numpy view of the packed 42-byte record (same field order as PACKET_FMT)
 PACKET_DTYPE = np.dtype([("magic", "S4"), ("agent", "u1"), ("x", "<f4"), ("y", "<f4"), ("yaw", "<f4"),

@@ -142,6 +142,16 @@ int qs_grid_to_pcd(qs_ctx *ctx, const int8_t *grid, int32_t h, int32_t w, double
 int qs_rasterise(qs_ctx *ctx, const double *xy, size_t n, double res, int32_t dims[2],
                  double origin[2], int8_t *grid);
 
+/* ---- frontiers  dual_bot_mapper.py:181-237, :948-956 -------------------------------------------
+ * OccupancyGrid.get_frontiers: interior FREE cells with a 4-neighbour UNKNOWN, row-major order
+ * (gx, gy pairs).  xy == NULL queries the count. */
+int qs_frontier_cells(qs_ctx *ctx, int32_t *xy, size_t cap, size_t *n_out);
+/* cluster_frontiers + the sums cluster_centroid_world divides: 4-connected clusters of at least
+ * min_cluster cells (reference: FRONTIER_MIN_CLUSTER = 3, :102) in the reference's order (by
+ * first cell, row-major); 5 values per cluster: size, first_gx, first_gy, sum_gx, sum_gy.
+ * stats5 == NULL queries the count. */
+int qs_frontier_clusters(qs_ctx *ctx, int32_t min_cluster, int64_t *stats5, size_t cap, size_t *n_out);
+
 /* ---- EKF  AgentFirmware_Bot1/ekf.cpp:5-92 ---------------------------------------------- */
 /* batched over bots: for k in 0..n: predict(omega_m[k], t[k]) then update(z_v[k], z_omega[k])
  * on bot_ids[k] (each bot at most once per call); do_update == 0: predict only */

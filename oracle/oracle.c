@@ -544,3 +544,65 @@ void qso_ekf_packet(double *f, double *prev, double t, double x, double y, doubl
     }
     prev[0] = t; prev[1] = yaw; prev[2] = enc; prev[3] = 1.0;
 }
+
+/* ---- frontiers  dual_bot_mapper.py:181-237 ------------------------------------------------ */
+/* get_frontiers :181-196: interior FREE cells with a 4-neighbour UNKNOWN, row-major (y outer). */
+long qso_frontier_cells(const int8_t *grid, int size, int32_t *xy, long cap)
+{
+    long n = 0;
+    for (int y = 1; y < size - 1; y++)
+        for (int x = 1; x < size - 1; x++) {
+            if (grid[(size_t)y * size + x] != CELL_FREE) continue;
+            if (grid[(size_t)y * size + x - 1] == CELL_UNKNOWN || grid[(size_t)y * size + x + 1] == CELL_UNKNOWN ||
+                grid[(size_t)(y - 1) * size + x] == CELL_UNKNOWN || grid[(size_t)(y + 1) * size + x] == CELL_UNKNOWN) {
+                if (n < cap) { xy[2 * n] = x; xy[2 * n + 1] = y; }
+                n++;
+            }
+        }
+    return n;
+}
+
+/* cluster_frontiers :198-231 (BFS flood fill over 4-neighbours, seeds in list order, clusters of
+ * fewer than min_cluster cells dropped) + the integer sums cluster_centroid_world :233-237 divides.
+ * stats per kept cluster: size, first_x, first_y, sum_x, sum_y.  Returns the cluster count. */
+long qso_frontier_clusters(const int32_t *xy, long n, int size, int min_cluster, int64_t *stats, long cap)
+{
+    size_t cells = (size_t)size * size;
+    uint8_t *in_set = calloc(cells, 1), *visited = calloc(cells, 1);
+    int32_t *queue = malloc((size_t)(n > 0 ? n : 1) * 2 * sizeof(int32_t));
+    for (long i = 0; i < n; i++) in_set[(size_t)xy[2 * i + 1] * size + xy[2 * i]] = 1;
+    long nc = 0;
+    static const int DX[4] = {-1, 1, 0, 0}, DY[4] = {0, 0, -1, 1};     /* :223 */
+    for (long i = 0; i < n; i++) {
+        int sx = xy[2 * i], sy = xy[2 * i + 1];
+        if (visited[(size_t)sy * size + sx]) continue;
+        long head = 0, tail = 0, cnt = 0;
+        int64_t sumx = 0, sumy = 0;
+        queue[0] = sx; queue[1] = sy; tail = 1;
+        while (head < tail) {
+            int cx = queue[2 * head], cy = queue[2 * head + 1];
+            head++;
+            size_t c = (size_t)cy * size + cx;
+            if (visited[c]) continue;
+            visited[c] = 1; cnt++; sumx += cx; sumy += cy;
+            for (int d = 0; d < 4; d++) {
+                int nx = cx + DX[d], ny = cy + DY[d];
+                if (nx < 0 || ny < 0 || nx >= size || ny >= size) continue;
+                size_t nb = (size_t)ny * size + nx;
+                if (in_set[nb] && !visited[nb]) {
+                    if (tail >= n) {           /* duplicates can be queued: grow on demand */
+                        /* each cell is queued at most 4 times; 4n is a safe bound */
+                    }
+                    queue = realloc(queue, (size_t)(tail + 1) * 2 * sizeof(int32_t));
+                    queue[2 * tail] = nx; queue[2 * tail + 1] = ny; tail++;
+                }
+            }
+        }
+        if (cnt >= min_cluster) {
+            if (nc < cap) { stats[5 * nc] = cnt; stats[5 * nc + 1] = sx; stats[5 * nc + 2] = sy; stats[5 * nc + 3] = sumx; stats[5 * nc + 4] = sumy; }
+            nc++;
+        }
+    }
+    free(in_set); free(visited); free(queue);
+    return nc;
+}

@@ -283,3 +283,39 @@ class OracleEKF:
 
     def cov(self, b):
         return self.f[b, 6:42].reshape(6, 6).copy()
+
+
+def frontier_cells(grid):
+    """OccupancyGrid.get_frontiers (dual_bot_mapper.py:181-196) -> int32 [n, 2] (gx, gy)."""
+    L = lib()
+    L.qso_frontier_cells.restype = C.c_long
+    L.qso_frontier_cells.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_long]
+    grid = np.ascontiguousarray(grid, dtype=np.int8)
+    size = grid.shape[0]
+    n = L.qso_frontier_cells(_ptr(grid), size, None, 0)
+    xy = np.zeros((n, 2), dtype=np.int32)
+    if n:
+        L.qso_frontier_cells(_ptr(grid), size, _ptr(xy), n)
+    return xy
+
+
+def frontier_clusters(cells_xy, size, min_cluster=3):
+    """cluster_frontiers (:198-231) -> int64 [k, 5]: size, first_x, first_y, sum_x, sum_y."""
+    L = lib()
+    L.qso_frontier_clusters.restype = C.c_long
+    L.qso_frontier_clusters.argtypes = [C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p, C.c_long]
+    xy = np.ascontiguousarray(cells_xy, dtype=np.int32)
+    k = L.qso_frontier_clusters(_ptr(xy), len(xy), size, min_cluster, None, 0)
+    st = np.zeros((k, 5), dtype=np.int64)
+    if k:
+        L.qso_frontier_clusters(_ptr(xy), len(xy), size, min_cluster, _ptr(st), k)
+    return st
+
+
+def cluster_centroids_world(stats, res, ox, oy):
+    """cluster_centroid_world (:233-237): mean index (true division) -> grid_to_world (:127-131)."""
+    out = []
+    for size, _, _, sx, sy in stats.tolist():
+        ax, ay = sx / size, sy / size
+        out.append((ox + (ax + 0.5) * res, oy + (ay + 0.5) * res))
+    return np.array(out, dtype=np.float64).reshape(-1, 2)

@@ -370,6 +370,28 @@ def main():
     adv2 = adversarial_stream(mapper, 3000, 4321, -3.0, 3.0)
     run_scenario(mapper, "adversarial_dense_200", adv2, 200, 0.05, -5.0, -5.0, 0.0)
 
+    # ---- frontier detection / clustering / centroids (dual_bot_mapper.py:181-237, :951-955) ----
+    fr = {}
+    for name in ("session_200", "session_512", "laps5_512", "adversarial_dense_200", "mixed_200"):
+        g = np.load(os.path.join(HERE, name + ".npz"))
+        size, res, ox, oy, _ = g["cfg"]
+        og = mapper.OccupancyGrid(int(size), res, ox, oy)
+        if "grid" in g.files:
+            og.grid = g["grid"].copy()
+        else:
+            continue
+        cells = og.get_frontiers()
+        clusters = og.cluster_frontiers(cells)
+        cents = [og.cluster_centroid_world(c) for c in clusters]
+        fr[name + "_cells"] = np.array(cells, dtype=np.int32).reshape(-1, 2)
+        fr[name + "_sizes"] = np.array([len(c) for c in clusters], dtype=np.int64)
+        fr[name + "_first"] = np.array([c[0] for c in clusters], dtype=np.int32).reshape(-1, 2)
+        fr[name + "_sums"] = np.array([[sum(p[0] for p in c), sum(p[1] for p in c)] for c in clusters],
+                                      dtype=np.int64).reshape(-1, 2)
+        fr[name + "_centroids"] = np.array(cents, dtype=np.float64).reshape(-1, 2)
+        print(f"[frontiers {name}] cells={len(cells)} clusters={len(clusters)}")
+    np.savez_compressed(os.path.join(HERE, "frontiers.npz"), **fr)
+
     with open(os.path.join(HERE, "kat.json"), "w") as f:
         json.dump(kat, f, indent=1, sort_keys=True)
     print(json.dumps(kat["session"], indent=1)[:1500])

@@ -409,3 +409,37 @@ def test_device_buffer_aliasing_and_nccl_allreduce_single_rank(pkg):
             dist.destroy_process_group()
         assert hashlib.sha256(m.grid_i8().tobytes()).digest() == g["grid_sha256"].tobytes()
         assert (m.counts()[0] == hits).all()
+
+
+@pytest.mark.parametrize("name", ["session_200", "session_512", "laps5_512", "adversarial_dense_200", "mixed_200"])
+def test_frontiers_vs_reference_golden(pkg, name):
+    """N1: get_frontiers / cluster_frontiers / cluster_centroid_world on the device grid
+    (dual_bot_mapper.py:181-237) against what the reference itself computed on its own grid."""
+    fr = load("frontiers")
+    g = load(name)
+    with make_mapper(pkg, g) as m:
+        m.ingest_array(g["datagrams"], g["lengths"])
+        cells = m.frontier_cells()
+        assert (cells == fr[name + "_cells"]).all()
+        st = m.frontier_clusters()
+        assert (st[:, 0] == fr[name + "_sizes"]).all()
+        assert (st[:, 1:3] == fr[name + "_first"]).all()
+        assert (st[:, 3:5] == fr[name + "_sums"]).all()
+        cents = np.array(m.frontier_centroids()).reshape(-1, 2)
+        assert (cents == fr[name + "_centroids"]).all()
+        assert m.occ_grid.get_frontiers()[:3] == [tuple(c) for c in fr[name + "_cells"][:3].tolist()]
+        # all clusters (min size 1) partition the frontier cells
+        assert int(m.frontier_clusters(min_cluster=1)[:, 0].sum()) == len(cells)
+
+
+def test_frontiers_full_size_vs_oracle(pkg):
+    replay = _replay(pkg)
+    session, _ = replay.telemetry_csv_to_packets()
+    stream = replay.multi_bot_stream(session, 64, 64 * 400)
+    with pkg.QuasarMapper(4096, 0.05, -102.4, -102.4, max_agent=64, bots_per_graph=2) as m:
+        m.ingest_array(stream)
+        grid = m.grid_i8()
+        cells = m.frontier_cells()
+        ocells = orc.frontier_cells(grid)
+        assert len(cells) > 5000 and (cells == ocells).all()
+        assert (m.frontier_clusters() == orc.frontier_clusters(ocells, 4096)).all()

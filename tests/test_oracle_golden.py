@@ -132,3 +132,19 @@ def test_session_kat_values():
     hits, misses = m.hits, m.misses
     assert ((hits + misses > 0) == (m.grid != -1)).all()
     assert hits.sum() + misses.sum() == m.n_cells_written
+
+
+@pytest.mark.parametrize("name", ["session_200", "session_512", "laps5_512", "adversarial_dense_200", "mixed_200"])
+def test_frontiers_vs_reference(name):
+    """N1: get_frontiers / cluster_frontiers / cluster_centroid_world (dual_bot_mapper.py:181-237)."""
+    fr = load("frontiers")
+    g = load(name)
+    size, res, ox, oy, _ = g["cfg"]
+    cells = orc.frontier_cells(g["grid"])
+    assert (cells == fr[name + "_cells"]).all()
+    st = orc.frontier_clusters(cells, int(size))
+    assert (st[:, 0] == fr[name + "_sizes"]).all()
+    assert (st[:, 1:3] == fr[name + "_first"]).all()
+    assert (st[:, 3:5] == fr[name + "_sums"]).all()
+    cents = orc.cluster_centroids_world(st, res, ox, oy)
+    assert (cents == fr[name + "_centroids"]).all()          # bit-exact: same integer sums, same fp64 ops
