@@ -443,3 +443,36 @@ def test_frontiers_full_size_vs_oracle(pkg):
         ocells = orc.frontier_cells(grid)
         assert len(cells) > 5000 and (cells == ocells).all()
         assert (m.frontier_clusters() == orc.frontier_clusters(ocells, 4096)).all()
+
+
+def test_udp_frontend_end_to_end(pkg):
+    """N2: the session's datagrams sent over real UDP to the front-end, ingested in whatever
+    batches the polls happen to form; the map must equal the reference's."""
+    import importlib, socket, time
+    fe = importlib.import_module(pkg.__name__ + ".udp_frontend")
+    g = load("mixed_200")
+    srv = socket.socket(socket.AF_INET, socket.SOCK_DGRAM)
+    srv.setsockopt(socket.SOL_SOCKET, socket.SO_RCVBUF, 1 << 22)
+    srv.bind(("127.0.0.1", 0))
+    port = srv.getsockname()[1]
+    with make_mapper(pkg, g) as m:
+        mc = fe.MissionControl(m, sock=srv)
+        tx = socket.socket(socket.AF_INET, socket.SOCK_DGRAM)
+        sent = 0
+        for d, n in zip(g["datagrams"], g["lengths"]):
+            if n == 0:
+                continue                      # an empty datagram is legal UDP but carries nothing to test
+            tx.sendto(d[:n].tobytes(), ("127.0.0.1", port)); sent += 1
+            if sent % 64 == 0:
+                time.sleep(0.002); mc.poll()
+        time.sleep(0.05)
+        while mc.poll():
+            pass
+        assert mc.datagrams == sent
+        assert hashlib.sha256(m.grid_i8().tobytes()).digest() == g["grid_sha256"].tobytes()
+        assert (m.closures(0)[0] == g["closures_idx"]).all()
+        assert mc.pkt_counts[1] + mc.pkt_counts[2] == int(g["accepted"].sum())
+        pk = mc.zone_tick(force=True)
+        assert pk[1] == g["zone_bytes_bot2"].tobytes() or np.allclose(
+            np.frombuffer(pk[1][4:], "<f4"), g["zone_bytes_bot2"][4:].view("<f4"), atol=1e-5)
+        tx.close(); mc.close()
