@@ -203,9 +203,29 @@ qs_ekf_ingest_kernel(size_t n, QsBatch b, const double *__restrict__ recv_time, 
     const int row_b = 4 * ((c <= 1) ? 6 * r + 3 : l);                                     //           col 3 of my row
     const int row_3 = 4 * (6 * r + 3), row_4 = 4 * (6 * r + 4), col_3 = 4 * (18 + c), col_4 = 4 * (24 + c);
 
-    for (size_t base = 0; base < n; base += QS_WAVE) {
+    // The stream is scanned 4 x 64 records per iteration; the accept / agent bytes of the NEXT group
+    // are requested before the current group is processed, so the scan never waits on them.
+    #define EKF_GROUP 4
+    unsigned char acc_n[EKF_GROUP], ag_n[EKF_GROUP];
+    #pragma unroll
+    for (int q = 0; q < EKF_GROUP; q++) {
+        const size_t i = (size_t)q * QS_WAVE + lane;
+        acc_n[q] = i < n ? b.accept[i] : 0; ag_n[q] = i < n ? b.agent[i] : 0;
+    }
+    for (size_t gbase = 0; gbase < n; gbase += EKF_GROUP * QS_WAVE) {
+        unsigned char acc_c[EKF_GROUP], ag_c[EKF_GROUP];
+        #pragma unroll
+        for (int q = 0; q < EKF_GROUP; q++) { acc_c[q] = acc_n[q]; ag_c[q] = ag_n[q]; }
+        #pragma unroll
+        for (int q = 0; q < EKF_GROUP; q++) {
+            const size_t i = gbase + (size_t)(EKF_GROUP + q) * QS_WAVE + lane;
+            acc_n[q] = i < n ? b.accept[i] : 0; ag_n[q] = i < n ? b.agent[i] : 0;
+        }
+      #pragma unroll
+      for (int sub = 0; sub < EKF_GROUP; sub++) {
+        const size_t base = gbase + (size_t)sub * QS_WAVE;
         const size_t i = base + lane;
-        const bool mine = i < n && b.accept[i] && b.agent[i] == bot;
+        const bool mine = i < n && acc_c[sub] && ag_c[sub] == bot;
         unsigned long long m = __ballot(mine);
         if (!m) continue;
         // ---- SIMD prologue: the chunk's fields (one coalesced load per array) and the wiring -------
@@ -249,6 +269,9 @@ qs_ekf_ingest_kernel(size_t n, QsBatch b, const double *__restrict__ recv_time, 
                 const double x0[6] = {ekf_rl(px_l, j), ekf_rl(py_l, j), ekf_rl(yaw_l, j), 0, 0, 0};
                 xr = x0[r]; P = (r == c) ? 1.0 : 0.0; last_t = ekf_rl(t_l, j); init = 1.0;
             } else if (kind == 1 && init != 0.0) {
+                // the predict-phase permutes only need last step's P: issue them first so that their
+                // LDS-pipeline latency hides behind the readlanes / sincos below
+                const double pa = ekf_perm(P, col_a), pb = ekf_perm(P, col_b);
                 const double t = ekf_rl(t_l, j), omega_m = ekf_rl(om_l, j), v_enc = ekf_rl(ve_l, j);
                 // ---- predict  ekf.cpp:26-68 ----
                 const double dt = t - last_t;
@@ -270,7 +293,7 @@ qs_ekf_ingest_kernel(size_t n, QsBatch b, const double *__restrict__ recv_time, 
                     // J P: (base + k1 * P[ra][c]) + k2 * P[3][c]
                     const double k1 = (r == 0) ? j02 : (r == 1) ? j12 : (r == 2) ? j25 : (r == 4) ? -1.0 : 0.0;
                     const double k2 = (r == 0) ? j03 : (r == 1) ? j13 : 0.0;
-                    const double JP = (((r == 4) ? 0.0 : P) + k1 * ekf_perm(P, col_a)) + k2 * ekf_perm(P, col_b);
+                    const double JP = (((r == 4) ? 0.0 : P) + k1 * pa) + k2 * pb;
                     // (J P) J^T: (base + JP[r][ca] * k1') + JP[r][3] * k2'
                     const double h1 = (c == 0) ? j02 : (c == 1) ? j12 : (c == 2) ? j25 : (c == 4) ? -1.0 : 0.0;
                     const double h2 = (c == 0) ? j03 : (c == 1) ? j13 : 0.0;
@@ -293,6 +316,7 @@ qs_ekf_ingest_kernel(size_t n, QsBatch b, const double *__restrict__ recv_time, 
                 P = (r == 5) ? tt + P : tt;
             }
         }
+      }
     }
     if (lane < 36) {
         f[6 + lane] = P;
