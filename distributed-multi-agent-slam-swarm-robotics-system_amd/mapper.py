@@ -43,13 +43,13 @@ class QuasarMapper:
         self.cfg = cfg
         self.size, self.res, self.ox, self.oy = size, resolution, origin_x, origin_y
         self.max_agent = max_agent
-        self.bots_per_graph = bots_per_graph if bots_per_graph > 0 else max_agent
-        self.n_graphs = (max_agent + self.bots_per_graph - 1) // self.bots_per_graph
         h = C.c_void_p()
-        rc = self._L.qs_create(C.byref(cfg), C.byref(h))
+        rc = self._L.qs_create(C.byref(cfg), C.byref(h))      # validates every field
         if rc != 0:
             raise QuasarError(f"qs_create failed ({rc}): {self._L.qs_last_error(None).decode()}")
         self._h = h
+        self.bots_per_graph = bots_per_graph if bots_per_graph > 0 else max_agent
+        self.n_graphs = (max_agent + self.bots_per_graph - 1) // self.bots_per_graph
         self._last_n = 0
         self.occ_grid = OccupancyGrid._attached(self)
         self.slam = PoseGraphSLAM._attached(self)

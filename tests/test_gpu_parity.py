@@ -476,3 +476,69 @@ def test_udp_frontend_end_to_end(pkg):
         assert pk[1] == g["zone_bytes_bot2"].tobytes() or np.allclose(
             np.frombuffer(pk[1][4:], "<f4"), g["zone_bytes_bot2"][4:].view("<f4"), atol=1e-5)
         tx.close(); mc.close()
+
+
+def test_long_session_capacity_growth(pkg):
+    """30 laps of the session (20.6 k packets) fed in uneven batches WITHOUT resets: the landmark log,
+    node pool, closure list and batch buffers all have to grow while the state is preserved."""
+    g = load("session_512")
+    pk = g["datagrams"][:, :42]
+    stream = np.tile(pk, (30, 1))
+    o = orc.OracleMapper(512, 0.05, -12.8, -12.8, 0.0)
+    o.feed_stream(stream)
+    with pkg.QuasarMapper(512, 0.05, -12.8, -12.8) as m:
+        pos, k = 0, 0
+        sizes = [5, 700, 1500, 64, 3000, 1, 9000, 20000]
+        while pos < len(stream):
+            m.ingest_array(stream[pos:pos + sizes[k % len(sizes)]]); pos += sizes[k % len(sizes)]; k += 1
+        assert (m.grid_i8() == o.grid).all()
+        idx, corr = m.closures(0); oi, oc = o.closures(0)
+        assert len(oi) > 400 and (idx == oi).all() and np.abs(corr - oc).max() < FLOAT_TOL
+        xy, ti = m.landmarks(0); oxy, oti = o.landmarks(0)
+        assert len(oti) > 3500 and (ti == oti).all() and np.abs(xy - oxy).max() < FLOAT_TOL
+        for b in (1, 2):
+            assert np.abs(m.drift(b) - o.drift(b)).max() < FLOAT_TOL
+        h, mi = m.counts()
+        assert (h == o.hits).all() and (mi == o.misses).all()
+        assert m.slam_sizes(0)[0] == len(stream)
+
+
+def test_api_edge_cases_and_errors(pkg):
+    with pytest.raises(pkg.QuasarError):
+        pkg.QuasarMapper(size=201)                              # size must be a multiple of 4
+    with pytest.raises(pkg.QuasarError):
+        pkg.QuasarMapper(max_agent=0)
+    with pkg.QuasarMapper(max_agent=3) as m:
+        assert m.ingest([]) == 0
+        m.ingest([b"", b"x", b"QSRL"])                           # nothing decodable: all dropped, nothing written
+        acc, pose = m.last_batch()
+        assert acc.tolist() == [0, 0, 0] and np.isnan(pose).all()
+        assert (m.grid_i8() == -1).all() and m.counters()["accepted"] == 0 and m.zone(1) is None
+        with pytest.raises(pkg.QuasarError):
+            m.drift(4)
+        with pytest.raises(pkg.QuasarError):
+            m.zone(0)
+        with pytest.raises(pkg.QuasarError):
+            m.closures(1)                                       # only graph 0 exists
+        P = pkg.protocol
+        one = P.pack_packet(3, 0.0, 0.0, 0.0, 0, 0, 0.5, 0.0, float("nan"), 3.0, 7)   # agent 3, odd landmark type 7
+        m.ingest([one])
+        acc, pose = m.last_batch()
+        assert acc.tolist() == [1] and pose[0].tolist() == [0.0, 0.0, 0.0]
+        o = orc.OracleMapper(max_agent=3); o.feed(one)
+        assert (m.grid_i8() == o.grid).all() and m.counters()["rays"] == 4 and m.counters()["hits"] == 1
+        xy, ti = m.landmarks(0)
+        assert ti.tolist() == [[7, 0]]                          # type > 5 lives in the side list, still logged
+        bad = P.pack_packet(1, float("inf"), 0.0, 0.0, 0, 0, 0.5, 0.5, 0.5, 0.5, 0)
+        m.ingest([bad])
+        assert m.last_batch()[0].tolist() == [0]                # non-finite pose: dropped (CPython would raise)
+    # landmark types above 5 and poses outside the bucket grid still close loops (side list)
+    P = pkg.protocol
+    pk = [P.pack_packet(1, 50.0 + 0.01 * (i % 3), 0.0, 0.0, i, 0, 0.0, 0.0, 0.0, 0.0, 9 if i % 10 == 0 else 0) for i in range(200)]
+    with pkg.QuasarMapper() as m:                               # 200x200 grid at (-5,-5): x = 50 is far outside
+        m.ingest(pk)
+        o = orc.OracleMapper()
+        for d in pk:
+            o.feed(d)
+        assert len(o.closures(0)[0]) > 0 and (m.closures(0)[0] == o.closures(0)[0]).all()
+        assert m.counters()["slam_misc_iters"] > 0 and (m.grid_i8() == -1).all()
