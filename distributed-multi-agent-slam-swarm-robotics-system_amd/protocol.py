@@ -92,3 +92,28 @@ def compute_bounding_box(points_x, points_y):
     if len(points_x) == 0:
         return None
     return (min(points_x), min(points_y), max(points_x), max(points_y))
+
+
+# ---- legacy Quasar-Lite v0 packet of the ROS bridge (server_nodes/udp_bridge.py:25-38) ----------
+# magic, agent_id, x, y, yaw, scan_count, 181 servo-sweep ranges; command back: 'CMD1', linear_x, angular_z
+PACKET_FMT_V0 = "<4sBfffH181f"
+PACKET_SIZE_V0 = struct.calcsize(PACKET_FMT_V0)      # 743
+CMD_FMT = "<4sff"
+PACKET_DTYPE_V0 = np.dtype([("magic", "S4"), ("agent", "u1"), ("x", "<f4"), ("y", "<f4"), ("yaw", "<f4"),
+                            ("scan_count", "<u2"), ("ranges", "<f4", (181,))])
+assert PACKET_DTYPE_V0.itemsize == PACKET_SIZE_V0
+
+
+def unpack_v0(data: bytes):
+    """udp_bridge.py:53-75: None unless the size and magic match; else (agent, x, y, yaw, ranges[181])."""
+    if len(data) != PACKET_SIZE_V0:
+        return None
+    rec = np.frombuffer(data, dtype=PACKET_DTYPE_V0)[0]
+    if rec["magic"] != b"QSRL":
+        return None
+    return int(rec["agent"]), float(rec["x"]), float(rec["y"]), float(rec["yaw"]), rec["ranges"].copy()
+
+
+def pack_cmd(linear_x, angular_z) -> bytes:
+    """udp_bridge.py:140-146."""
+    return struct.pack(CMD_FMT, b"CMD1", linear_x, angular_z)

@@ -76,3 +76,16 @@ def test_product_package_never_imports_the_oracle():
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in txt.lower() or f == "__init__.py" and False, \
                     f"{f} mentions the oracle: the product path must not use it"
+
+
+def test_legacy_v0_bridge_formats():
+    """N4: the ROS bridge's 743-byte v0 packet and CMD1 reply (server_nodes/udp_bridge.py:25-38, :140-146)."""
+    pkg = load_pkg()
+    P = pkg.protocol
+    assert P.PACKET_SIZE_V0 == 743 and struct.calcsize(P.CMD_FMT) == 12
+    ranges = np.linspace(0.1, 4.0, 181, dtype=np.float32)
+    raw = struct.pack(P.PACKET_FMT_V0, b"QSRL", 3, 1.0, -2.0, 0.5, 181, *ranges.tolist())
+    agent, x, y, yaw, rg = P.unpack_v0(raw)
+    assert (agent, x, y, yaw) == (3, 1.0, -2.0, 0.5) and (rg == ranges).all()
+    assert P.unpack_v0(raw[:-1]) is None and P.unpack_v0(b"XXXX" + raw[4:]) is None
+    assert P.pack_cmd(0.25, -1.0) == struct.pack("<4sff", b"CMD1", 0.25, -1.0)
