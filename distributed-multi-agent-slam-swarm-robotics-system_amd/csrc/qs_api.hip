@@ -1,6 +1,7 @@
 // qs_api.hip -- the C ABI of include/quasar_slam.h: context, device memory, and the per-batch
 // pipeline  decode (K0) -> SLAM drift (K4) -> raycast (K1) [-> EKF (K5)]  on one HIP stream.
 #include <math.h>
+#include <algorithm>
 #include <stdio.h>
 #include <string.h>
 
@@ -847,6 +848,106 @@ extern "C" int qs_rasterise(qs_ctx *c, const double *xy, size_t n, double res, i
     hipFree(dxy); hipFree(dbox); hipFree(dg);
     if (e != hipSuccess) return qs_fail(c, QS_E_HIP, "qs_rasterise", e);
     return rc;
+}
+
+// ---- ICP / voxel down-sample (map_merger.py:45-60; Open3D semantics, parity unpinned) ------------------
+extern "C" int qs_icp(qs_ctx *c, const double *src_xy, size_t n_src, const double *dst_xy, size_t n_dst, double max_dist,
+                      int32_t max_iter, double rel_fitness, double rel_rmse, double T[9], double *fitness, double *rmse,
+                      int32_t *iters)
+{
+    ARGCHK(c, c != nullptr && T != nullptr && fitness != nullptr && rmse != nullptr);
+    ARGCHK(c, n_src > 0 && n_dst > 0 && src_xy && dst_xy && max_dist > 0 && max_iter >= 0);
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t nb = (n_src + 255) / 256;
+    double2 *d_src = nullptr, *d_dst = nullptr; int *d_corr = nullptr; double *d_d2 = nullptr, *d_part = nullptr, *d_out = nullptr;
+    hipError_t e = hipMalloc((void **)&d_src, n_src * sizeof(double2));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_dst, n_dst * sizeof(double2));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_corr, n_src * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_d2, n_src * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_part, nb * 6 * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_out, 6 * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_src, src_xy, n_src * sizeof(double2), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_dst, dst_xy, n_dst * sizeof(double2), hipMemcpyHostToDevice, c->stream);
+    double tc = 1.0, ts = 0.0, tx = 0.0, ty = 0.0;          // accumulated transform
+    double out[6] = {0};
+    const double zero4[4] = {0, 0, 0, 0};
+    auto evaluate = [&](double &fit, double &rm) -> hipError_t {
+        hipError_t ee = qs_launch_icp_nn(c, d_src, n_src, d_dst, n_dst, max_dist * max_dist, d_corr, d_d2);
+        if (ee == hipSuccess) ee = qs_launch_icp_sums(c, d_src, n_src, d_dst, d_corr, d_d2, 0, zero4, d_part, d_out);
+        if (ee == hipSuccess) ee = hipMemcpyAsync(out, d_out, sizeof out, hipMemcpyDeviceToHost, c->stream);
+        if (ee == hipSuccess) ee = hipStreamSynchronize(c->stream);
+        fit = out[0] / (double)n_src;
+        rm = out[0] > 0 ? sqrt(out[1] / out[0]) : 0.0;
+        return ee;
+    };
+    double fit = 0, rm = 0;
+    int it = 0;
+    if (e == hipSuccess) e = evaluate(fit, rm);
+    for (; e == hipSuccess && it < max_iter; it++) {
+        double uc = 1.0, us = 0.0, ux = 0.0, uy = 0.0;       // ComputeTransformation: identity without correspondences
+        if (out[0] > 0) {
+            const double nn = out[0];
+            const double means[4] = {out[2] / nn, out[3] / nn, out[4] / nn, out[5] / nn};
+            double o2[6];
+            e = qs_launch_icp_sums(c, d_src, n_src, d_dst, d_corr, d_d2, 1, means, d_part, d_out);
+            if (e == hipSuccess) e = hipMemcpyAsync(o2, d_out, sizeof o2, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            if (e != hipSuccess) break;
+            const double theta = atan2(o2[1], o2[0]);
+            uc = cos(theta); us = sin(theta);
+            ux = means[2] - (uc * means[0] - us * means[1]);
+            uy = means[3] - (us * means[0] + uc * means[1]);
+        }
+        // transformation = update * transformation
+        const double nc = uc * tc - us * ts, ns = us * tc + uc * ts;
+        const double nx = uc * tx - us * ty + ux, ny = us * tx + uc * ty + uy;
+        tc = nc; ts = ns; tx = nx; ty = ny;
+        e = qs_launch_icp_transform(c, d_src, n_src, uc, us, ux, uy);
+        const double bfit = fit, brm = rm;
+        if (e == hipSuccess) e = evaluate(fit, rm);
+        if (e == hipSuccess && fabs(bfit - fit) < rel_fitness && fabs(brm - rm) < rel_rmse) { it++; break; }
+    }
+    hipFree(d_src); hipFree(d_dst); hipFree(d_corr); hipFree(d_d2); hipFree(d_part); hipFree(d_out);
+    if (e != hipSuccess) return qs_fail(c, QS_E_HIP, "qs_icp", e);
+    T[0] = tc; T[1] = -ts; T[2] = tx; T[3] = ts; T[4] = tc; T[5] = ty; T[6] = 0; T[7] = 0; T[8] = 1;
+    *fitness = fit; *rmse = rm;
+    if (iters) *iters = it;
+    return QS_OK;
+}
+
+extern "C" int qs_voxel_downsample(qs_ctx *c, const double *xy, size_t n, double voxel, double *out_xy, size_t cap, size_t *n_out)
+{
+    ARGCHK(c, c != nullptr && n_out != nullptr && voxel > 0);
+    *n_out = 0;
+    if (n == 0) return QS_OK;
+    ARGCHK(c, xy != nullptr);
+    HIPCHK(c, hipSetDevice(c->device));
+    double mnx = xy[0], mny = xy[1];
+    for (size_t i = 1; i < n; i++) { if (xy[2 * i] < mnx) mnx = xy[2 * i]; if (xy[2 * i + 1] < mny) mny = xy[2 * i + 1]; }
+    mnx -= voxel * 0.5; mny -= voxel * 0.5;                 // voxel_min_bound = min_bound - voxel_size / 2
+    double2 *d = nullptr; unsigned long long *dk = nullptr;
+    std::vector<unsigned long long> keys(n);
+    hipError_t e = hipMalloc((void **)&d, n * sizeof(double2));
+    if (e == hipSuccess) e = hipMalloc((void **)&dk, n * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemcpyAsync(d, xy, n * sizeof(double2), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = qs_launch_voxel_keys(c, d, n, mnx, mny, voxel, dk);
+    if (e == hipSuccess) e = hipMemcpyAsync(keys.data(), dk, n * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(d); hipFree(dk);
+    if (e != hipSuccess) return qs_fail(c, QS_E_HIP, "qs_voxel_downsample", e);
+    // group by voxel (ascending key), average in input order: a handful of points per ROS callback
+    std::vector<size_t> order(n);
+    for (size_t i = 0; i < n; i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return keys[a] < keys[b]; });
+    size_t k = 0;
+    for (size_t p = 0; p < n;) {
+        size_t q = p; double sx = 0, sy = 0;
+        while (q < n && keys[order[q]] == keys[order[p]]) { sx += xy[2 * order[q]]; sy += xy[2 * order[q] + 1]; q++; }
+        if (out_xy && k < cap) { out_xy[2 * k] = sx / (double)(q - p); out_xy[2 * k + 1] = sy / (double)(q - p); }
+        k++; p = q;
+    }
+    *n_out = k;
+    return QS_OK;
 }
 
 // ---- frontiers ------------------------------------------------------------------------------------

@@ -192,6 +192,14 @@ size_t qs_frontier_workspace_bytes(const qs_ctx *c);
 hipError_t qs_launch_frontier_label(qs_ctx *c, void *ws, bool with_clusters);
 hipError_t qs_launch_frontier_compact(qs_ctx *c, void *ws, int mode, int phase, int *d_xy, long long *d_stats, size_t cap);
 unsigned long long *qs_frontier_total_ptr(const qs_ctx *c, void *ws);
+// icp.hip
+hipError_t qs_launch_icp_nn(qs_ctx *c, const double2 *src, size_t n_src, const double2 *dst, size_t n_dst,
+                            double max_d2, int *corr, double *d2);
+hipError_t qs_launch_icp_sums(qs_ctx *c, const double2 *src, size_t n_src, const double2 *dst, const int *corr,
+                              const double *d2, int pass, const double means[4], double *partial, double *out6);
+hipError_t qs_launch_icp_transform(qs_ctx *c, double2 *pts, size_t n, double cs, double sn, double tx, double ty);
+hipError_t qs_launch_voxel_keys(qs_ctx *c, const double2 *pts, size_t n, double minx, double miny, double voxel,
+                                unsigned long long *keys);
 // ekf.hip
 hipError_t qs_launch_ekf_ingest(qs_ctx *c, size_t n, const double *d_time, hipStream_t st);
 hipError_t qs_launch_ekf_step(qs_ctx *c, const int *d_bots, const double *d_omega, const double *d_t,

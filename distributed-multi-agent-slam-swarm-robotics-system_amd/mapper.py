@@ -265,6 +265,27 @@ class QuasarMapper:
                   "qs_rasterise")
         return grid, origin
 
+    # -- ICP / voxel down-sample: map_merger.py:45-60 (Open3D semantics, parity unpinned) ---------
+    def icp(self, src_xy, dst_xy, max_dist=1.0, max_iter=30, rel_fitness=1e-6, rel_rmse=1e-6):
+        """registration_icp(source, target, max_dist, I, PointToPoint, max_iteration) on planar clouds.
+        Returns (T 3x3, fitness, inlier_rmse, iterations)."""
+        a = np.ascontiguousarray(src_xy, dtype=np.float64); b = np.ascontiguousarray(dst_xy, dtype=np.float64)
+        T = np.zeros(9, dtype=np.float64)
+        fit, rm, it = C.c_double(), C.c_double(), C.c_int32()
+        self._chk(self._L.qs_icp(self._h, _ptr(a), len(a), _ptr(b), len(b), max_dist, max_iter, rel_fitness, rel_rmse,
+                                 _ptr(T), C.byref(fit), C.byref(rm), C.byref(it)), "qs_icp")
+        return T.reshape(3, 3), fit.value, rm.value, it.value
+
+    def voxel_downsample(self, xy, voxel):
+        a = np.ascontiguousarray(xy, dtype=np.float64)
+        n = C.c_size_t()
+        self._chk(self._L.qs_voxel_downsample(self._h, _ptr(a), len(a), voxel, None, 0, C.byref(n)), "qs_voxel_downsample")
+        out = np.zeros((n.value, 2), dtype=np.float64)
+        if n.value:
+            self._chk(self._L.qs_voxel_downsample(self._h, _ptr(a), len(a), voxel, _ptr(out), n.value, C.byref(n)),
+                      "qs_voxel_downsample")
+        return out
+
     # -- frontiers: dual_bot_mapper.py:181-237, :948-956 ----------------------------------------
     def frontier_cells(self):
         """OccupancyGrid.get_frontiers() -> int32 [n, 2] (gx, gy), row-major order."""

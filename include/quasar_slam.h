@@ -142,6 +142,19 @@ int qs_grid_to_pcd(qs_ctx *ctx, const int8_t *grid, int32_t h, int32_t w, double
 int qs_rasterise(qs_ctx *ctx, const double *xy, size_t n, double res, int32_t dims[2],
                  double origin[2], int8_t *grid);
 
+/* ---- ICP registration and voxel down-sampling: MapMerger.map_callback, map_merger.py:45-60 ------
+ * registration_icp(source, target, max_dist, identity, PointToPoint, max_iteration) on planar
+ * clouds (Open3D semantics; parity unpinned: Open3D is not available).  T = 3x3 row-major planar
+ * rigid transform source -> target; fitness = #correspondences / n_src; rmse over correspondences;
+ * stops early when |d fitness| < rel_fitness and |d rmse| < rel_rmse (Open3D defaults: 1e-6). */
+int qs_icp(qs_ctx *ctx, const double *src_xy, size_t n_src, const double *dst_xy, size_t n_dst,
+           double max_dist, int32_t max_iter, double rel_fitness, double rel_rmse, double T[9],
+           double *fitness, double *rmse, int32_t *iters);
+/* PointCloud.voxel_down_sample(voxel): mean of the points of each voxel, ascending voxel order
+ * (Open3D's order is unspecified).  out_xy == NULL queries the count. */
+int qs_voxel_downsample(qs_ctx *ctx, const double *xy, size_t n, double voxel, double *out_xy,
+                        size_t cap, size_t *n_out);
+
 /* ---- frontiers  dual_bot_mapper.py:181-237, :948-956 -------------------------------------------
  * OccupancyGrid.get_frontiers: interior FREE cells with a 4-neighbour UNKNOWN, row-major order
  * (gx, gy pairs).  xy == NULL queries the count. */

@@ -319,3 +319,61 @@ def cluster_centroids_world(stats, res, ox, oy):
         ax, ay = sx / size, sy / size
         out.append((ox + (ax + 0.5) * res, oy + (ay + 0.5) * res))
     return np.array(out, dtype=np.float64).reshape(-1, 2)
+
+
+# ---- ICP / voxel down-sample restated from Open3D's published algorithm (map_merger.py:45-60).
+# PARITY UNPINNED: Open3D is not importable; these follow the same steps as csrc/icp.hip in numpy.
+def icp_planar(src, dst, max_dist=1.0, max_iter=30, rel_fitness=1e-6, rel_rmse=1e-6):
+    src = np.asarray(src, dtype=np.float64).copy(); dst = np.asarray(dst, dtype=np.float64)
+    T = np.eye(3)
+
+    def evaluate(p):
+        d2 = ((p[:, None, :] - dst[None, :, :]) ** 2).sum(-1)
+        j = d2.argmin(1)                      # ties -> lowest index
+        dmin = d2[np.arange(len(p)), j]
+        ok = dmin < max_dist * max_dist
+        n = int(ok.sum())
+        return ok, j, n / len(p), (np.sqrt(dmin[ok].sum() / n) if n else 0.0)
+
+    ok, j, fit, rm = evaluate(src)
+    it = 0
+    while it < max_iter:
+        U = np.eye(3)
+        if ok.any():
+            a, b = src[ok], dst[j[ok]]
+            am, bm = a.mean(0), b.mean(0)
+            ac, bc = a - am, b - bm
+            theta = np.arctan2((ac[:, 0] * bc[:, 1] - ac[:, 1] * bc[:, 0]).sum(), (ac[:, 0] * bc[:, 0] + ac[:, 1] * bc[:, 1]).sum())
+            c, s = np.cos(theta), np.sin(theta)
+            R = np.array([[c, -s], [s, c]])
+            U[:2, :2] = R; U[:2, 2] = bm - R @ am
+        T = U @ T
+        src = src @ U[:2, :2].T + U[:2, 2]
+        bfit, brm = fit, rm
+        ok, j, fit, rm = evaluate(src)
+        it += 1
+        if abs(bfit - fit) < rel_fitness and abs(brm - rm) < rel_rmse:
+            break
+    return T, fit, rm, it
+
+
+def voxel_downsample(xy, voxel):
+    xy = np.asarray(xy, dtype=np.float64)
+    if len(xy) == 0:
+        return xy.reshape(0, 2)
+    mn = xy.min(0) - voxel * 0.5
+    v = np.floor((xy - mn) / voxel).astype(np.int64)
+    key = v[:, 1] * (1 << 32) + v[:, 0]
+    order = np.argsort(key, kind="stable")
+    out, p = [], 0
+    while p < len(xy):
+        q = p
+        while q < len(xy) and key[order[q]] == key[order[p]]:
+            q += 1
+        sel = order[p:q]
+        sx = sy = 0.0
+        for i in sel:
+            sx += xy[i, 0]; sy += xy[i, 1]
+        out.append((sx / (q - p), sy / (q - p)))
+        p = q
+    return np.array(out, dtype=np.float64).reshape(-1, 2)

@@ -542,3 +542,64 @@ def test_api_edge_cases_and_errors(pkg):
             o.feed(d)
         assert len(o.closures(0)[0]) > 0 and (m.closures(0)[0] == o.closures(0)[0]).all()
         assert m.counters()["slam_misc_iters"] > 0 and (m.grid_i8() == -1).all()
+
+
+def _rigid(theta, tx, ty):
+    c, s = np.cos(theta), np.sin(theta)
+    return np.array([[c, -s, tx], [s, c, ty], [0, 0, 1.0]])
+
+
+def test_icp_and_voxel_downsample(pkg):
+    """N3 (parity unpinned: Open3D absent): the HIP ICP against the numpy restatement of the same
+    published algorithm, and recovery of known rigid transforms on rasterised session maps."""
+    g = load("session_512")
+    with pkg.QuasarMapper() as m:
+        dst = m.grid_to_pcd(g["grid"], 0.05, -12.8, -12.8)                       # 437 occupied cells
+        for theta, tx, ty in ((np.radians(3.0), 0.12, -0.08), (np.radians(-5.0), -0.2, 0.15), (0.0, 0.0, 0.0)):
+            Tt = _rigid(theta, tx, ty)
+            src = dst @ np.linalg.inv(Tt)[:2, :2].T + np.linalg.inv(Tt)[:2, 2]   # so that Tt maps src onto dst
+            T, fit, rm, it = m.icp(src, dst, 1.0, 30)
+            To, fo, ro, io = orc.icp_planar(src, dst, 1.0, 30)
+            assert it == io and abs(fit - fo) < 1e-12 and abs(rm - ro) < 1e-9
+            np.testing.assert_allclose(T, To, rtol=0, atol=1e-9)
+            assert fit == 1.0 and rm < 2e-2
+            np.testing.assert_allclose(T, Tt, rtol=0, atol=3e-2)                  # recovered up to grid ambiguity
+            assert abs(np.linalg.det(T[:2, :2]) - 1.0) < 1e-12
+        # partial overlap and a far-away cloud (no correspondences -> fitness 0, identity)
+        T, fit, rm, it = m.icp(dst[:200] + [0.03, 0.02], dst, 1.0, 30)
+        assert fit == 1.0 and rm < 0.05
+        T, fit, rm, it = m.icp(dst + [500.0, 0.0], dst, 1.0, 30)
+        assert fit == 0.0 and rm == 0.0 and (T == np.eye(3)).all() and it == 1
+        # voxel down-sample
+        cloud = np.concatenate([dst, dst + [0.011, 0.007], dst[:50] + [0.4, 0.0]])
+        v = m.voxel_downsample(cloud, 0.05)
+        vo = orc.voxel_downsample(cloud, 0.05)
+        assert v.shape == vo.shape and len(v) < len(cloud) and np.abs(v - vo).max() < 1e-12
+        assert m.voxel_downsample(np.zeros((0, 2)), 0.05).shape == (0, 2)
+
+
+def test_map_merger_flow(pkg):
+    """MapMerger.map_callback (map_merger.py:35-62) end to end: first map adopted, a shifted copy
+    registered and merged, an unrelated map rejected by the fitness gate."""
+    import importlib
+    merger = importlib.import_module(pkg.__name__ + ".merger")
+    g = load("session_512")
+    grid = g["grid"]
+    with pkg.QuasarMapper() as m:
+        mm = merger.MapMerger(m)
+        assert mm.map_callback(np.full((8, 8), -1, dtype=np.int8), 0.05, 0.0, 0.0) is None      # empty local map :37
+        out, origin = mm.map_callback(grid, 0.05, -12.8, -12.8, agent_id=1)                    # adopted :40-43
+        # publish_global_map truncates ((p - min) / res).astype(int) (:109-110): neighbouring cells can
+        # collapse, exactly as in the reference; the CPU restatement is the yardstick, not 437
+        want, worigin = orc.rasterise(orc.grid_to_pcd(grid, 0.05, -12.8, -12.8), 0.05)
+        assert (out == want).all() and (origin == worigin).all() and mm.last_registration is None
+        # agent 2 reports the same room in a frame shifted by (+0.10, -0.15): ICP must pull it back
+        out2, origin2 = mm.map_callback(grid, 0.05, -12.8 + 0.10, -12.8 - 0.15, agent_id=2)
+        T, fit, rm, it = mm.last_registration
+        assert fit >= 0.6 and abs(T[0, 2] + 0.10) < 0.03 and abs(T[1, 2] - 0.15) < 0.03
+        assert 350 <= (out2 == 100).sum() <= 2 * 437 and 437 <= len(mm.global_xy) <= 2 * 437   # merged + voxel-averaged
+        # an unrelated map far away: no correspondences, fitness 0 < 0.6 -> rejected, global unchanged (:54-56)
+        before = mm.global_xy.copy()
+        far = np.full((64, 64), -1, dtype=np.int8); far[10:20, 10:20] = 100
+        assert mm.map_callback(far, 0.05, 300.0, 300.0, agent_id=3) is None
+        assert (mm.global_xy == before).all()
