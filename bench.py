@@ -41,18 +41,20 @@ def parse():
     ap.add_argument("--raycast-mode", type=int, default=0)
     ap.add_argument("--no-counts", action="store_true", help="tri-state stamps only (no hit/miss counters)")
     ap.add_argument("--ekf", type=int, default=1, help="run the per-bot EKF stage (1) or not (0)")
+    ap.add_argument("--bots", type=int, default=2, help="bots per GPU (2 = configs[1], the judged workload; 64 = configs[2] shape)")
+    ap.add_argument("--bots-per-graph", type=int, default=0, help="bots sharing one pose graph (0 = all)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=200000, help="packets of the same stream timed on the CPU")
     return ap.parse_args()
 
 
-def cpu_baseline(stream, grid, sample, ekf, times):
+def cpu_baseline(stream, grid, sample, ekf, times, bots=2, bpg=0):
     """The oracle (C restatement of the reference path, 1 thread) on a bounded prefix of the
     same stream.  Reported, never the thing shipped."""
     from oracle import oracle as orc
     n = min(sample, len(stream))
     half = grid * 0.05 / 2
-    m = orc.OracleMapper(grid, 0.05, -half, -half, 0.0, max_agent=2)
+    m = orc.OracleMapper(grid, 0.05, -half, -half, 0.0, max_agent=bots, bots_per_graph=bpg)
     if ekf:
         m.enable_ekf(0.0107)
     t0 = time.perf_counter()
@@ -108,8 +110,8 @@ def main():
     B, G = args.batch, args.grid
     half = G * 0.05 / 2
     session, _ = replay.telemetry_csv_to_packets()
-    stream = replay.cycle_stream(session, B)
-    if world > 1:   # this rank's two bots live in their own room tile (8 m pitch)
+    stream = replay.cycle_stream(session, B) if args.bots == 2 else replay.multi_bot_stream(session, args.bots, B)
+    if world > 1 and args.bots == 2:   # this rank's two bots live in their own room tile (8 m pitch)
         rec = stream.view(pkg.protocol.PACKET_DTYPE).reshape(-1)
         rec["x"] = (rec["x"].astype(np.float64) + 8.0 * (rank % 8) - 28.0).astype(np.float32)
         rec["y"] = (rec["y"].astype(np.float64) + 8.0 * (rank // 8)).astype(np.float32)
@@ -117,7 +119,8 @@ def main():
     d_time = torch.arange(B, dtype=torch.float64, device=dev) * 0.25
     torch.cuda.synchronize()
 
-    m = pkg.QuasarMapper(G, 0.05, -half, -half, max_agent=2, enable_counts=not args.no_counts,
+    m = pkg.QuasarMapper(G, 0.05, -half, -half, max_agent=args.bots, bots_per_graph=args.bots_per_graph,
+                         enable_counts=not args.no_counts,
                          enable_ekf=bool(args.ekf), device=local_rank, raycast_mode=args.raycast_mode,
                          seq_stride=world)
     stream_t = torch.cuda.current_stream()
@@ -169,11 +172,12 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic: reference generator's 2-bot session cycled",
-            "config": {"workload": f"configs[1]: 2-bot stream, {G}x{G} grid, res 0.05, {B} packets/step/GPU, "
+            "config": {"workload": f"{'configs[1]: 2-bot' if args.bots == 2 else str(args.bots) + '-bot'} stream, {G}x{G} grid, res 0.05, {B} packets/step/GPU, "
                                    f"fresh session per step, decode+loop-closure+raycast"
                                    f"{'+EKF' if args.ekf else ''}{'+allreduce' if world > 1 else ''}",
                        "batch": B, "grid": G, "counts": not args.no_counts, "ekf": bool(args.ekf),
-                       "raycast_mode": args.raycast_mode, "sharding": f"by agent, {world} x 2 bots"},
+                       "raycast_mode": args.raycast_mode, "bots_per_gpu": args.bots, "bots_per_graph": args.bots_per_graph or args.bots,
+                       "sharding": f"by agent, {world} x {args.bots} bots"},
             "stages_ms_per_step": {k: (v[0] / max(v[1], 1)) for k, v in stages.items() if v[1]},
             "counters_per_step": cnt,
             "roofline": {"bound": "hbm", "kernel": "K1 raycast stage (qs_rays + 2 scans + qs_scatter + qs_raster)",
@@ -185,7 +189,8 @@ def main():
                          "avg_launch_ms": ray_avg_s * 1e3},
         }
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(stream, G, args.cpu_sample, bool(args.ekf), np.arange(B) * 0.25)
+            out["cpu_baseline"] = cpu_baseline(stream, G, args.cpu_sample, bool(args.ekf), np.arange(B) * 0.25,
+                                                args.bots, args.bots_per_graph)
         print(json.dumps(out))
     m.close()
     if world > 1:
