@@ -367,6 +367,14 @@ hipError_t qs_launch_raycast_tiled(qs_ctx *c, size_t n, uint64_t seq0)
     // upper bound on raster work items: every record in a full chunk, plus one partial chunk per tile
     size_t max_items = (4 * n_rays) / QT_CHUNK + (size_t)ws.n_tiles + 8;
     if (max_items > 4 * n_rays) max_items = 4 * n_rays;
+    if (lds > 32 * 1024) {
+        // large grids (up to 8192^2: 16384 tiles) need more dynamic LDS than the 64 KiB default allows
+        // next to the static arrays; the CU has 160 KiB
+        hipError_t ea = hipFuncSetAttribute((const void *)qs_rays_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (ea == hipSuccess) ea = hipFuncSetAttribute((const void *)qs_rays_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (ea == hipSuccess) ea = hipFuncSetAttribute((const void *)qs_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (ea != hipSuccess) return ea;
+    }
     if (c->cfg.enable_counts) {
         hipLaunchKernelGGL(qs_rays_kernel<true>, dim3(ws.nwg), dim3(QT_BIN_BLOCK), lds, c->stream, n, c->b, c->geom, ws,
                            c->d_stamps, c->d_counts, ord_base, ord_stride, c->d_zone, c->cfg.max_agent, c->d_counters);

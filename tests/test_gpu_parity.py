@@ -603,3 +603,25 @@ def test_map_merger_flow(pkg):
         far = np.full((64, 64), -1, dtype=np.int8); far[10:20, 10:20] = 100
         assert mm.map_callback(far, 0.05, 300.0, 300.0, agent_id=3) is None
         assert (mm.global_xy == before).all()
+
+
+def test_grid_8192_configs4(pkg):
+    """BASELINE configs[4] grid size: 8192^2 (16384 tiles: 64 KiB LDS histogram in the binning passes).
+    64 bots on a 16 m pitch, checked against the oracle."""
+    replay = _replay(pkg)
+    session, _ = replay.telemetry_csv_to_packets()
+    n = 64 * 300
+    stream = replay.multi_bot_stream(session, 64, n, pitch=40.0, tiles_per_row=8, origin=(-190.0, -190.0))
+    o = orc.OracleMapper(8192, 0.05, -204.8, -204.8, 0.0, max_agent=64, bots_per_graph=2)
+    assert o.feed_stream(stream) == n
+    with pkg.QuasarMapper(8192, 0.05, -204.8, -204.8, max_agent=64, bots_per_graph=2) as m:
+        m.ingest_array(stream)
+        grid = m.grid_i8()
+        assert (grid == o.grid).all()
+        h, mi = m.counts()
+        assert (h == o.hits).all() and (mi == o.misses).all()
+        assert int((grid != -1).sum()) > 100000
+        for gr in (0, 7, 31):
+            assert (m.closures(gr)[0] == o.closures(gr)[0]).all()
+        cells = m.frontier_cells()
+        assert (cells == orc.frontier_cells(grid)).all()
