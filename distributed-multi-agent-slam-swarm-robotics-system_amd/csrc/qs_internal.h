@@ -146,8 +146,6 @@ struct qs_ctx {
 
     // timing
     bool timing = false;
-    hipEvent_t ev[QS_STAGE_N][2]{};
-    bool ev_created = false;
     struct Pending { int stage; hipEvent_t a, b; };
     std::vector<Pending> pending;
     std::vector<hipEvent_t> ev_pool;

@@ -182,7 +182,7 @@ int qs_counters(qs_ctx *ctx, uint64_t out[QS_CNT_N]);
 /* HIP-event timing of the pipeline stages on the context's stream.  enable != 0 brackets
  * each stage of every ingest with events; qs_stage_times returns accumulated ms and the
  * launch count per stage since the last call with reset != 0. */
-enum { QS_STAGE_DECODE = 0, QS_STAGE_SLAM, QS_STAGE_RAYCAST, QS_STAGE_EKF, QS_STAGE_BIN,
+enum { QS_STAGE_DECODE = 0, QS_STAGE_SLAM, QS_STAGE_RAYCAST, QS_STAGE_EKF,
        QS_STAGE_N };
 int qs_timing_enable(qs_ctx *ctx, int32_t enable);
 int qs_stage_times(qs_ctx *ctx, double ms[QS_STAGE_N], uint64_t launches[QS_STAGE_N],
