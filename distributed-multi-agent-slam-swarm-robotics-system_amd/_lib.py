@@ -86,6 +86,7 @@ SIGNATURES = {
     "qs_slam_sizes": (_i32, [_vp, _i32, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     "qs_slam_closures": (_i32, [_vp, _i32, _vp, _vp, _sz]),
     "qs_slam_landmarks": (_i32, [_vp, _i32, _vp, _vp, _sz]),
+    "qs_slam_add_poses": (_i32, [_vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "qs_drift": (_i32, [_vp, _i32, _vp]),
     "qs_zone": (_i32, [_vp, _i32, _vp, C.POINTER(_i32)]),
     "qs_zone_packet": (_i32, [_vp, _i32, _i32, _vp]),

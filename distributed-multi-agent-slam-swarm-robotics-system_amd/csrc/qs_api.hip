@@ -711,6 +711,71 @@ extern "C" int qs_slam_landmarks(qs_ctx *c, int32_t graph, double *xy, int64_t *
     return QS_OK;
 }
 
+// PoseGraphSLAM.add_pose, batched (object API): poses as given, no rays, no EKF.
+extern "C" int qs_slam_add_poses(qs_ctx *c, const double *x, const double *y, const uint8_t *agent, const uint8_t *landmark,
+                                 size_t n, uint8_t *closed, double *corr2)
+{
+    ARGCHK(c, c != nullptr);
+    if (n == 0) return QS_OK;
+    ARGCHK(c, x && y && agent && landmark);
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = ensure_batch(c, n);
+    if (rc != QS_OK) return rc;
+    const int G = c->n_graphs, nb = c->cfg.max_agent + 2;
+    std::vector<unsigned char> acc(n);
+    std::vector<unsigned long long> gb((size_t)G * 2, 0);
+    std::vector<unsigned int> aev(nb, 0);
+    for (size_t i = 0; i < n; i++) {
+        const bool ok = agent[i] >= 1 && agent[i] <= c->cfg.max_agent && isfinite(x[i]) && isfinite(y[i]);
+        acc[i] = ok ? 1 : 0;
+        if (!ok) continue;
+        const int g = (agent[i] - 1) / c->bots_per_graph;
+        gb[2 * g]++;
+        if (landmark[i]) { gb[2 * g + 1]++; aev[agent[i]]++; }
+    }
+    HIPCHK(c, hipMemcpyAsync(c->b.accept, acc.data(), n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->b.agent, agent, n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->b.lm, landmark, n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->b.px, x, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->b.py, y, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_graph_batch, gb.data(), gb.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->sb.agent_ev, aev.data(), aev.size() * sizeof(unsigned int), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));           // host vectors above go out of use
+    c->b.n = n;
+    rc = reserve_graphs_for_batch(c, n);
+    if (rc != QS_OK) return rc;
+    std::vector<QsGraphDev> before(G), after(G);
+    HIPCHK(c, hipMemcpyAsync(before.data(), c->d_graphs, (size_t)G * sizeof(QsGraphDev), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, qs_launch_slam(c, n, true));
+    HIPCHK(c, hipMemcpyAsync(after.data(), c->d_graphs, (size_t)G * sizeof(QsGraphDev), hipMemcpyDeviceToHost, c->stream));
+    std::vector<long long> node(n);
+    HIPCHK(c, hipMemcpyAsync(node.data(), c->sb.node, n * sizeof(long long), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->last_has_poses = false;
+    if (closed) memset(closed, 0, n);
+    if (corr2) for (size_t i = 0; i < 2 * n; i++) corr2[i] = 0.0;
+    if (!closed && !corr2) return QS_OK;
+    for (int g = 0; g < G; g++) {
+        const long long k0 = before[g].n_cls, k1 = after[g].n_cls;
+        if (k1 <= k0) continue;
+        const size_t m = (size_t)(k1 - k0);
+        std::vector<long long> cn(m); std::vector<double> dx(m), dy(m);
+        HIPCHK(c, hipMemcpy(cn.data(), after[g].cl_node_idx + k0, m * 8, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(dx.data(), after[g].cl_dx + k0, m * 8, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(dy.data(), after[g].cl_dy + k0, m * 8, hipMemcpyDeviceToHost));
+        size_t q = 0;     // closures and poses of one graph are both in node order
+        for (size_t i = 0; i < n && q < m; i++) {
+            if (!acc[i] || (agent[i] - 1) / c->bots_per_graph != g) continue;
+            if (node[i] == cn[q]) {
+                if (closed) closed[i] = 1;
+                if (corr2) { corr2[2 * i] = dx[q]; corr2[2 * i + 1] = dy[q]; }
+                q++;
+            }
+        }
+    }
+    return QS_OK;
+}
+
 extern "C" int qs_drift(qs_ctx *c, int32_t bot, double out[2])
 {
     ARGCHK(c, c != nullptr && out);

@@ -159,7 +159,7 @@ hipError_t qs_launch_decode(qs_ctx *c, const unsigned char *d_pkts, size_t n, si
                             const unsigned short *d_lens);
 #define QS_SLAM_IDX_BLOCK 1024   // records per block of the SLAM index tables
 // slam.hip
-hipError_t qs_launch_slam(qs_ctx *c, size_t n);
+hipError_t qs_launch_slam(qs_ctx *c, size_t n, bool raw_pose = false);
 int qs_slam_blocks(size_t n);
 // raycast.hip
 hipError_t qs_launch_raycast_direct(qs_ctx *c, size_t n, uint64_t seq0);

@@ -200,8 +200,10 @@ __global__ void __launch_bounds__(CH_THREADS)
 qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGeom bg, int bots_per_graph,
                      int max_agent, int win, int min_between, double r2thr, double corr,
                      double *__restrict__ drift, long long *__restrict__ last_closure,
-                     unsigned long long *__restrict__ counters)
+                     unsigned long long *__restrict__ counters, int raw_pose)
 {
+    // raw_pose: poses are used as given (PoseGraphSLAM.add_pose object API: the caller has already
+    // applied its drift correction, dual_bot_mapper.py:855-857 precede :908)
     const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     QsGraphDev G = graphs[g];
     const int bot0 = g * bots_per_graph + 1;
@@ -263,8 +265,8 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
             first = rl64(idx, 0);
             inw = have && idx < first + win;                        // a contiguous prefix of the lanes
             if (!inw) { a = 0; type = 0; }
-            x = px + s_drift[a][0];                                 // rx += cdx  :856
-            y = py + s_drift[a][1];                                 // ry += cdy  :857
+            x = raw_pose ? px : px + s_drift[a][0];                 // rx += cdx  :856
+            y = raw_pose ? py : py + s_drift[a][1];                 // ry += cdy  :857
             elig = inw && (idx - s_last[a] >= min_between);         // :304
             bucket_prepare(x, y, type, bg, dir_slab, kb, nbm);
             if (lane < 32) {
@@ -411,7 +413,7 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
             if (cmask) {
                 // later events of a closing agent in this window are posed (and stored) with the new drift
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-                if (inw && !closes && s_last[a] >= first && s_last[a] < idx) {
+                if (!raw_pose && inw && !closes && s_last[a] >= first && s_last[a] < idx) {
                     x = px + s_drift[a][0];
                     y = py + s_drift[a][1];
                     bucket_prepare(x, y, type, bg, dir_slab, kb, nbm);
@@ -520,7 +522,7 @@ qs_slam_pose_kernel(size_t n, QsBatch b, QsSlamBatch sb)
     b.ry[i] = b.py[i] + dy;
 }
 
-hipError_t qs_launch_slam(qs_ctx *c, size_t n)
+hipError_t qs_launch_slam(qs_ctx *c, size_t n, bool raw_pose)
 {
     if (n == 0) return hipSuccess;
     QsSlamBatch sb = c->sb;
@@ -534,7 +536,8 @@ hipError_t qs_launch_slam(qs_ctx *c, size_t n)
                        c->stream, n, c->b, sb, c->d_graphs, c->bots_per_graph, G);
     hipLaunchKernelGGL(qs_slam_chain_kernel, dim3(G), dim3(CH_THREADS), 0, c->stream, c->d_graphs, sb, c->bg,
                        c->bots_per_graph, c->cfg.max_agent, c->win, c->cfg.min_poses_between, c->r2_threshold,
-                       c->cfg.closure_correction, c->d_drift, c->d_last_closure, c->d_counters);
+                       c->cfg.closure_correction, c->d_drift, c->d_last_closure, c->d_counters, raw_pose ? 1 : 0);
+    if (raw_pose) return hipGetLastError();
     hipLaunchKernelGGL(qs_slam_pose_kernel, dim3((unsigned int)((n + 255) / 256)), dim3(256), 0, c->stream, n, c->b, sb);
     return hipGetLastError();
 }

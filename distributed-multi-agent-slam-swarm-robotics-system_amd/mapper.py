@@ -201,6 +201,16 @@ class QuasarMapper:
             self._chk(self._L.qs_slam_landmarks(self._h, graph, _ptr(xy), _ptr(ti), n), "qs_slam_landmarks")
         return xy, ti
 
+    def slam_add_poses(self, x, y, agent, landmark):
+        """Batched PoseGraphSLAM.add_pose on poses as given -> (closed uint8 [n], corr float64 [n, 2])."""
+        xs = np.ascontiguousarray(x, dtype=np.float64); ys = np.ascontiguousarray(y, dtype=np.float64)
+        ag = np.ascontiguousarray(agent, dtype=np.uint8); lm = np.ascontiguousarray(landmark, dtype=np.uint8)
+        n = len(xs)
+        closed = np.zeros(n, dtype=np.uint8); corr = np.zeros((n, 2), dtype=np.float64)
+        self._chk(self._L.qs_slam_add_poses(self._h, _ptr(xs), _ptr(ys), _ptr(ag), _ptr(lm), n, _ptr(closed), _ptr(corr)),
+                  "qs_slam_add_poses")
+        return closed, corr
+
     def drift(self, bot):
         out = np.zeros(2, dtype=np.float64)
         self._chk(self._L.qs_drift(self._h, bot, _ptr(out)), "qs_drift")
@@ -421,3 +431,13 @@ class PoseGraphSLAM:
     @property
     def n_nodes(self):
         return self._m.slam_sizes(self._g)[0]
+
+    def add_pose(self, x, y, yaw, agent_id, landmark_type, timestamp=0.0):
+        """dual_bot_mapper.py:273-290: returns (closure_detected, correction_dx, correction_dy).  The
+        pose is used as given (the caller applies its own drift correction first, :855-857)."""
+        closed, corr = self._m.slam_add_poses([x], [y], [agent_id], [landmark_type])
+        return bool(closed[0]), float(corr[0, 0]), float(corr[0, 1])
+
+    def get_correction_for_agent(self, agent_id):
+        """:328-338: the sum of this agent's closure corrections, i.e. its drift correction."""
+        return tuple(float(v) for v in self._m.drift(agent_id))

@@ -117,6 +117,12 @@ int qs_slam_sizes(qs_ctx *ctx, int32_t graph, int64_t *n_nodes, int64_t *n_landm
 int qs_slam_closures(qs_ctx *ctx, int32_t graph, int64_t *idx2, double *corr2, size_t cap);
 /* slam.landmarks: (x, y), (type, node_idx) in insertion order  :269, :288 */
 int qs_slam_landmarks(qs_ctx *ctx, int32_t graph, double *xy, int64_t *type_idx, size_t cap);
+/* PoseGraphSLAM.add_pose(x, y, yaw, agent_id, landmark_type, timestamp) -> (closure_detected,
+ * correction_dx, correction_dy), batched  :273-290.  Object API: the poses are used AS GIVEN -- the
+ * caller has already applied its drift correction, as main() does (:855-857) before it calls
+ * add_pose (:908).  No rays are cast.  closed / corr2 (n x 2) may be NULL. */
+int qs_slam_add_poses(qs_ctx *ctx, const double *x, const double *y, const uint8_t *agent,
+                      const uint8_t *landmark, size_t n, uint8_t *closed, double *corr2);
 /* drift_correction[bot]  :782, :910-914 */
 int qs_drift(qs_ctx *ctx, int32_t bot, double out[2]);
 

@@ -625,3 +625,30 @@ def test_grid_8192_configs4(pkg):
             assert (m.closures(gr)[0] == o.closures(gr)[0]).all()
         cells = m.frontier_cells()
         assert (cells == orc.frontier_cells(grid)).all()
+
+
+def test_pose_graph_object_api_add_pose(pkg):
+    """PoseGraphSLAM.add_pose driven exactly as main() drives it (:850-857, :908-914): the caller keeps
+    drift_correction, applies it, calls add_pose per packet and adds the returned correction.  Must
+    reproduce the reference's closures on the golden session, one pose at a time and in batches."""
+    g = load("session_512")
+    want_idx, want_corr = g["closures_idx"], g["closures_corr"]
+    poses, agents = g["pose_xyyaw"], g["pose_agent"]               # reference poses AFTER drift (what add_pose saw)
+    lm = g["datagrams"][:, 41]
+    with pkg.QuasarMapper(512, 0.05, -12.8, -12.8) as m:
+        got = []
+        for i in range(len(poses)):
+            closed, dx, dy = m.slam.add_pose(poses[i, 0], poses[i, 1], poses[i, 2], int(agents[i]), int(lm[i]), 0.0)
+            if closed:
+                got.append((i, dx, dy))
+        assert [k for k, _, _ in got] == want_idx[:, 1].tolist()
+        np.testing.assert_allclose(np.array([[a, b] for _, a, b in got]), want_corr, rtol=0, atol=FLOAT_TOL)
+        assert (m.closures(0)[0] == want_idx).all() and m.slam.n_nodes == 687
+        np.testing.assert_allclose(m.slam.get_correction_for_agent(1), g["drift"][0], rtol=0, atol=FLOAT_TOL)
+        assert (m.grid_i8() == -1).all()                              # no rays were cast
+    with pkg.QuasarMapper(512, 0.05, -12.8, -12.8) as m:              # the same in two batches
+        c1, k1 = m.slam_add_poses(poses[:300, 0], poses[:300, 1], agents[:300], lm[:300])
+        c2, k2 = m.slam_add_poses(poses[300:, 0], poses[300:, 1], agents[300:], lm[300:])
+        closed = np.concatenate([c1, c2]); corr = np.concatenate([k1, k2])
+        assert np.nonzero(closed)[0].tolist() == want_idx[:, 1].tolist()
+        np.testing.assert_allclose(corr[closed == 1], want_corr, rtol=0, atol=FLOAT_TOL)
