@@ -652,3 +652,29 @@ def test_pose_graph_object_api_add_pose(pkg):
         closed = np.concatenate([c1, c2]); corr = np.concatenate([k1, k2])
         assert np.nonzero(closed)[0].tolist() == want_idx[:, 1].tolist()
         np.testing.assert_allclose(corr[closed == 1], want_corr, rtol=0, atol=FLOAT_TOL)
+
+
+@pytest.mark.parametrize("size,res,span", [(4, 0.5, 1.5), (8, 0.05, 0.5), (68, 0.05, 2.5), (132, 0.013, 1.2),
+                                           (200, 0.2, 25.0), (1028, 0.05, 30.0)])
+@pytest.mark.parametrize("mode", [1, 2])
+def test_odd_geometries_adversarial(pkg, size, res, span, mode):
+    """Grids that are tiny, not multiples of the 64-cell raster tile, coarse or fine (long rays take the
+    direct path inside the tiled pipeline), fed a random stream that pokes every edge: out-of-bounds
+    poses, NaN / inf / boundary distances."""
+    replay = _replay(pkg)
+    origin = -size * res / 2
+    stream = replay.adversarial_stream(3000, seed=size * 7 + mode, lo=-span, hi=span)
+    rec = stream.view(pkg.protocol.PACKET_DTYPE).reshape(-1)
+    rng = np.random.default_rng(size)
+    k = rng.integers(0, 3000, 200)
+    rec["front"][k[:50]] = np.nan; rec["left"][k[50:100]] = np.inf; rec["back"][k[100:150]] = 0.05; rec["right"][k[150:]] = 1.2
+    o = orc.OracleMapper(size, res, origin, origin, 0.0)
+    o.feed_stream(stream)
+    with pkg.QuasarMapper(size, res, origin, origin, raycast_mode=mode) as m:
+        m.ingest_array(stream[:1111]); m.ingest_array(stream[1111:])
+        assert (m.grid_i8() == o.grid).all()
+        h, mi = m.counts()
+        assert (h == o.hits).all() and (mi == o.misses).all()
+        assert m.counters()["cells"] == o.n_cells_written
+        assert (m.closures(0)[0] == o.closures(0)[0]).all()
+        assert (m.frontier_cells() == orc.frontier_cells(o.grid)).all()
