@@ -39,6 +39,13 @@
 #define QT_MAX_WG 512                    // persistent workgroups of pass A / C (2 per CU)
 #define QT_MAX_TILES 16384               // LDS histogram limit: 64 KiB (8192^2 cells)
 #define QT_NO_RAY ((int)0x80000000)
+#ifndef QT_RASTER_WGS
+#define QT_RASTER_WGS 1024               // persistent raster workgroups (4 per CU)
+#endif
+#ifndef QT_PITCH
+#define QT_PITCH 67                      // LDS row pitch in cells: bank = (x + 3 y) mod 32, see qs_raster_kernel
+#endif
+#define QT_LDS_CELLS (QT_TILE * QT_PITCH)
 
 struct QtWorkspace {
     unsigned int *table;         // [nwg][n_tiles] per-workgroup record counts -> exclusive offsets
@@ -238,79 +245,183 @@ qs_scatter_kernel(size_t n, QsBatch b, QtWorkspace ws, int size, unsigned long l
 }
 
 // ---- pass D: LDS raster + merge -------------------------------------------------------------------
+// Persistent workgroups: workgroup w takes the contiguous run of work items [w * per, (w + 1) * per).
+// Items are in tile order, so consecutive items mostly belong to the same tile (two robots in one
+// room: ~300 items per tile); the LDS tile keeps accumulating across them and is merged into the HBM
+// grid only when the tile changes.  Every merge of a shared tile is ~3000 device-scope atomics on
+// the same few hundred cache lines as every other workgroup of that tile, so merging once per run
+// instead of once per item takes most of that traffic away (and the empty workgroups of a
+// one-item-per-workgroup launch with it).
+#define QT_FLUSH_ITEMS 31                // 16-bit LDS counters: <= 31 * QT_CHUNK writes per cell between merges
+
+template <bool COUNTS>
+__device__ inline void qt_merge_tile(unsigned int *s_stamp, unsigned int *s_cnt, unsigned int *s_cells, int tid, int tile,
+                                     bool exclusive, const QtWorkspace &ws, int size, unsigned int *__restrict__ stamps,
+                                     unsigned long long *__restrict__ counts)
+{
+    // one 64-cell (256 B) grid row per wave-instruction.  A thread owns QT_CELLS / QT_BLOCK cells of
+    // one column; all its grid loads are issued before the first store so an exclusive merge costs
+    // one HBM round trip, not one per row.
+    constexpr int PER = QT_CELLS / QT_BLOCK;
+    constexpr int ROWS = QT_BLOCK / QT_TILE;              // rows covered by the workgroup per step
+    const int tx0 = (tile % ws.tiles_x) << QT_TILE_SHIFT, ty0 = (tile / ws.tiles_x) << QT_TILE_SHIFT;
+    const int mx = tid & (QT_TILE - 1), my = tid >> QT_TILE_SHIFT;
+    // cells beyond the grid edge (partial tiles) are never written in LDS: v == 0 / kk == 0 there
+    const size_t g0 = (size_t)(ty0 + my) * size + (tx0 + mx);
+    const size_t gstep = (size_t)ROWS * size;
+    unsigned int writes = 0;
+    {   // stamps: cell-wise max  (:150 / :156 last writer wins)
+        unsigned int v[PER], g[PER];
+        #pragma unroll
+        for (int q = 0; q < PER; q++) v[q] = s_stamp[(my + q * ROWS) * QT_PITCH + mx];
+        if (exclusive) {
+            #pragma unroll
+            for (int q = 0; q < PER; q++) g[q] = v[q] != 0 ? stamps[g0 + q * gstep] : 0xffffffffu;
+            #pragma unroll
+            for (int q = 0; q < PER; q++) if (v[q] > g[q]) stamps[g0 + q * gstep] = v[q];
+        } else {
+            #pragma unroll
+            for (int q = 0; q < PER; q++) if (v[q] != 0) atomicMax(&stamps[g0 + q * gstep], v[q]);
+        }
+    }
+    if (COUNTS) {   // hit / miss counters: cell-wise sum
+        unsigned int kk[PER];
+        unsigned long long gc[PER];
+        #pragma unroll
+        for (int q = 0; q < PER; q++) {
+            kk[q] = s_cnt[(my + q * ROWS) * QT_PITCH + mx];
+            writes += (kk[q] >> 16) + (kk[q] & 0xffffu);
+        }
+        if (exclusive) {
+            #pragma unroll
+            for (int q = 0; q < PER; q++) gc[q] = kk[q] != 0 ? counts[g0 + q * gstep] : 0;
+            #pragma unroll
+            for (int q = 0; q < PER; q++)
+                if (kk[q] != 0) counts[g0 + q * gstep] = gc[q] + (((unsigned long long)(kk[q] >> 16) << 32) | (kk[q] & 0xffffu));
+        } else {
+            #pragma unroll
+            for (int q = 0; q < PER; q++)
+                if (kk[q] != 0) atomicAdd(&counts[g0 + q * gstep], ((unsigned long long)(kk[q] >> 16) << 32) | (kk[q] & 0xffffu));
+        }
+        // cell writes (statistic): the LDS counters hold them
+        #pragma unroll
+        for (int off = 32; off > 0; off >>= 1) writes += __shfl_xor(writes, off);
+        if ((tid & (QS_WAVE - 1)) == 0 && writes) atomicAdd(s_cells, writes);
+    }
+}
+
 template <bool COUNTS>
 __global__ void __launch_bounds__(QT_BLOCK)
 qs_raster_kernel(QtWorkspace ws, int size, unsigned int *__restrict__ stamps,
                  unsigned long long *__restrict__ counts, unsigned long long *__restrict__ counters)
 {
-    __shared__ unsigned int s_stamp[QT_CELLS];
-    __shared__ unsigned int s_cnt[COUNTS ? QT_CELLS : 1];    // hi16 hits, lo16 misses (<= QT_CHUNK each)
+    // + 64 scratch cells: a lane whose current cell is outside the tile (or whose walk has ended)
+    // aims its two LDS atomics at its own scratch word instead of branching around them
+    __shared__ unsigned int s_stamp[QT_LDS_CELLS + QS_WAVE];
+    __shared__ unsigned int s_cnt[COUNTS ? QT_LDS_CELLS + QS_WAVE : 1];   // hi16 hits, lo16 misses
     __shared__ unsigned int s_cells;
     const int tid = threadIdx.x;
     const unsigned int n_items = ws.chunk_base[ws.n_tiles];
-    const unsigned int item = blockIdx.x;
-    if (item >= n_items) return;
-    // tile of this work item: last t with chunk_base[t] <= item
-    int lo = 0, hi = ws.n_tiles;
-    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (ws.chunk_base[mid] <= item) lo = mid; else hi = mid; }
-    const int tile = lo;
-    const unsigned int cnt = ws.tile_count[tile];
-    const unsigned int rb = ws.tile_base[tile] + (item - ws.chunk_base[tile]) * QT_CHUNK;
-    const unsigned int re = min(rb + QT_CHUNK, ws.tile_base[tile] + cnt);
-    const bool exclusive = cnt <= QT_CHUNK;          // the only work item of this tile in this launch
-    const int tx0 = (tile % ws.tiles_x) << QT_TILE_SHIFT, ty0 = (tile / ws.tiles_x) << QT_TILE_SHIFT;
-    const int tw = min(QT_TILE, size - tx0), th = min(QT_TILE, size - ty0);
-
-    for (int c = tid; c < QT_CELLS / 4; c += QT_BLOCK) {
-        ((uint4 *)s_stamp)[c] = make_uint4(0, 0, 0, 0);
-        if (COUNTS) ((uint4 *)s_cnt)[c] = make_uint4(0, 0, 0, 0);
-    }
+    const unsigned int per = (n_items + gridDim.x - 1) / gridDim.x;
+    const unsigned int first = blockIdx.x * per;
+    const unsigned int last = min(first + per, n_items);
+    if (first >= last) return;
     if (tid == 0) s_cells = 0;
-    __syncthreads();
+    // tile of the first work item: last t with chunk_base[t] <= first
+    int tile;
+    {
+        int lo = 0, hi = ws.n_tiles;
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (ws.chunk_base[mid] <= first) lo = mid; else hi = mid; }
+        tile = lo;
+    }
+    // Lane -> record mapping.  Records of a tile are in arrival order, so neighbouring records are the
+    // four rays of one packet and the packets of the same bot a few centimetres apart: 64 consecutive
+    // records walk nearly the same cells in lockstep and their LDS atomics serialise on the same
+    // addresses.  Each wave therefore takes 8 groups of 8 consecutive records (two packets: 8
+    // different rays), the groups QT_BLOCK / 8 records apart.
+    const int lane = tid & (QS_WAVE - 1), wave = tid >> 6;
+    const unsigned int slot = (unsigned int)((lane >> 3) * (QT_BLOCK / 8) + wave * 8 + (lane & 7));
+    const int scratch4 = 4 * (QT_LDS_CELLS + lane);     // byte offset of this lane's scratch cell
+    unsigned int wave_cells = 0;                        // wave-uniform count of cell writes (!COUNTS)
+    int cur_tile = -1, since_flush = 0;
 
-    unsigned int my_cells = 0;
-    for (unsigned int j = rb + tid; j < re; j += QT_BLOCK) {
-        const uint4 rec = ws.recs[j];
-        int x = (short)(rec.x & 0xffffu), y = (short)(rec.x >> 16);
-        const int x1 = (short)(rec.y & 0xffffu), y1 = (short)(rec.y >> 16);
-        const unsigned int key_free = rec.z;
-        const bool valid = rec.w & 1u;
-        const int dx = abs(x1 - x), dy = abs(y1 - y);             // dual_bot_mapper.py:161-165
-        const int sx = x < x1 ? 1 : -1, sy = y < y1 ? 1 : -1;
-        int err = dx - dy;
-        for (;;) {
-            const bool last = (x == x1 && y == y1);                // :169
-            if ((!last || valid) && (unsigned int)x < (unsigned int)tw && (unsigned int)y < (unsigned int)th) {
-                const int c = (y << QT_TILE_SHIFT) + x;
-                atomicMax(&s_stamp[c], key_free | (last ? 1u : 0u));          // :150 / :156
-                if (COUNTS) atomicAdd(&s_cnt[c], last ? 0x10000u : 1u);
-                my_cells++;
+    for (unsigned int item = first; item < last; item++) {
+        while (ws.chunk_base[tile + 1] <= item) tile++;          // tiles without records own no items
+        if (tile != cur_tile || since_flush == QT_FLUSH_ITEMS) {
+            if (cur_tile >= 0) {
+                __syncthreads();
+                const bool excl = ws.chunk_base[cur_tile] >= first && ws.chunk_base[cur_tile + 1] <= last;
+                qt_merge_tile<COUNTS>(s_stamp, s_cnt, &s_cells, tid, cur_tile, excl, ws, size, stamps, counts);
+                __syncthreads();
             }
-            if (last) break;
-            const int e2 = 2 * err;                                // :171-177
-            if (e2 > -dy) { err -= dy; x += sx; }
-            if (e2 < dx) { err += dx; y += sy; }
+            for (int c = tid; c < QT_LDS_CELLS / 4; c += QT_BLOCK) {
+                ((uint4 *)s_stamp)[c] = make_uint4(0, 0, 0, 0);
+                if (COUNTS) ((uint4 *)s_cnt)[c] = make_uint4(0, 0, 0, 0);
+            }
+            __syncthreads();
+            cur_tile = tile; since_flush = 0;
+        }
+        since_flush++;
+        const unsigned int rb = ws.tile_base[tile] + (item - ws.chunk_base[tile]) * QT_CHUNK;
+        const unsigned int re = min(rb + QT_CHUNK, ws.tile_base[tile] + ws.tile_count[tile]);
+        const int tx0 = (tile % ws.tiles_x) << QT_TILE_SHIFT, ty0 = (tile / ws.tiles_x) << QT_TILE_SHIFT;
+        const int tw = min(QT_TILE, size - tx0), th = min(QT_TILE, size - ty0);
+        const unsigned int tw4 = 4u * (unsigned int)tw;
+        for (unsigned int j0 = rb; j0 < re; j0 += QT_BLOCK) {
+            const unsigned int j = j0 + slot;
+            // Walk state in major/minor form.  The walk of dual_bot_mapper.py:166-178 advances its
+            // major axis in EVERY iteration and reaches (x1, y1) after exactly max(dx, dy) of them
+            // (tests/test_oracle_golden.py::test_bresenham_major_axis_property), so with
+            //   E = err (x-major, dx >= dy) or -err (y-major)
+            // the pair of tests `e2 > -dy`, `e2 < dx` (:172-177) is ONE test per cell: the minor axis
+            // steps iff 2 E < dmaj, i.e. E < (dmaj + 1) >> 1, and E += minor ? dmaj - dmin : -dmin.
+            // The last cell (x1, y1) is the only one that can be marked occupied (:150): it is written
+            // before the loop, and `x == x1 and y == y1` (:169) becomes a countdown over the
+            // k = max(dx, dy) free cells.
+            int x4 = 0, y = 0, k = 0, E = 0, H = 0, incA = 0, incB = 0, sx_c = 0, sx_n = 0, sy_c = 0, sy_n = 0;
+            unsigned int key_free = 0;
+            bool wl = false;
+            if (j < re) {
+                const uint4 rec = ws.recs[j];
+                const int x = (short)(rec.x & 0xffffu), x1 = (short)(rec.y & 0xffffu);
+                const int y1 = (short)(rec.y >> 16);
+                y = (short)(rec.x >> 16);
+                key_free = rec.z;
+                const int dx = abs(x1 - x), dy = abs(y1 - y);                  // :161-162
+                const int sx4 = x < x1 ? 4 : -4, sy = y < y1 ? 1 : -1;         // :163-164 (x in bytes)
+                const bool xmaj = dx >= dy;
+                const int dmaj = xmaj ? dx : dy, dmin = xmaj ? dy : dx;
+                k = dmaj; E = dmaj - dmin; H = (dmaj + 1) >> 1; incA = dmaj - dmin; incB = -dmin;
+                sx_c = sx4; sx_n = xmaj ? sx4 : 0; sy_c = sy; sy_n = xmaj ? 0 : sy;
+                x4 = x << 2;
+                wl = (rec.w & 1u) && (unsigned int)x1 < (unsigned int)tw && (unsigned int)y1 < (unsigned int)th;
+                if (wl) {                                                      // :148-150 occupied end cell
+                    const int c = y1 * QT_PITCH + x1;
+                    atomicMax(&s_stamp[c], key_free | 1u);
+                    if (COUNTS) atomicAdd(&s_cnt[c], 0x10000u);
+                }
+            }
+            if (!COUNTS) wave_cells += (unsigned int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(wl));
+            for (int it = 0; __any(it < k); it++) {                            // :152-156 free cells
+                const bool w = it < k && (unsigned int)x4 < tw4 && (unsigned int)y < (unsigned int)th;
+                const int a = w ? y * (4 * QT_PITCH) + x4 : scratch4;
+                atomicMax((unsigned int *)((char *)s_stamp + a), key_free);
+                if (COUNTS) atomicAdd((unsigned int *)((char *)s_cnt + a), 1u);
+                if (!COUNTS) wave_cells += (unsigned int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(w));
+                const bool minor = E < H;
+                E += minor ? incA : incB;
+                x4 += minor ? sx_c : sx_n;
+                y += minor ? sy_c : sy_n;
+            }
         }
     }
-    if (my_cells) atomicAdd(&s_cells, my_cells);
+    if (!COUNTS && lane == 0 && wave_cells) atomicAdd(&s_cells, wave_cells);
     __syncthreads();
-
-    // merge the touched cells into the HBM grid: one 64-cell (256 B) row per wave-instruction
-    for (int c = tid; c < QT_CELLS; c += QT_BLOCK) {
-        const int x = c & (QT_TILE - 1), y = c >> QT_TILE_SHIFT;
-        const unsigned int v = s_stamp[c];
-        if (v != 0 && x < tw && y < th) {
-            const size_t gidx = (size_t)(ty0 + y) * size + (tx0 + x);
-            if (exclusive) { if (v > stamps[gidx]) stamps[gidx] = v; }
-            else atomicMax(&stamps[gidx], v);
-            if (COUNTS) {
-                const unsigned int k = s_cnt[c];
-                const unsigned long long add = ((unsigned long long)(k >> 16) << 32) | (k & 0xffffu);
-                if (exclusive) counts[gidx] += add;
-                else atomicAdd(&counts[gidx], add);
-            }
-        }
+    {
+        const bool excl = ws.chunk_base[cur_tile] >= first && ws.chunk_base[cur_tile + 1] <= last;
+        qt_merge_tile<COUNTS>(s_stamp, s_cnt, &s_cells, tid, cur_tile, excl, ws, size, stamps, counts);
     }
+    __syncthreads();
     if (tid == 0 && s_cells) atomicAdd(&counters[QS_CNT_CELLS], (unsigned long long)s_cells);
 }
 
@@ -388,11 +499,12 @@ hipError_t qs_launch_raycast_tiled(qs_ctx *c, size_t n, uint64_t seq0)
     hipLaunchKernelGGL(qs_tile_scan_kernel, dim3(1), dim3(1024), 0, c->stream, ws);
     hipLaunchKernelGGL(qs_scatter_kernel, dim3(ws.nwg), dim3(QT_BIN_BLOCK), lds, c->stream, n, c->b, ws,
                        c->cfg.size, ord_base, ord_stride);
+    const unsigned int raster_wgs = (unsigned int)(max_items < QT_RASTER_WGS ? max_items : QT_RASTER_WGS);
     if (c->cfg.enable_counts)
-        hipLaunchKernelGGL(qs_raster_kernel<true>, dim3((unsigned int)max_items), dim3(QT_BLOCK), 0, c->stream, ws,
+        hipLaunchKernelGGL(qs_raster_kernel<true>, dim3(raster_wgs), dim3(QT_BLOCK), 0, c->stream, ws,
                            c->cfg.size, c->d_stamps, c->d_counts, c->d_counters);
     else
-        hipLaunchKernelGGL(qs_raster_kernel<false>, dim3((unsigned int)max_items), dim3(QT_BLOCK), 0, c->stream, ws,
+        hipLaunchKernelGGL(qs_raster_kernel<false>, dim3(raster_wgs), dim3(QT_BLOCK), 0, c->stream, ws,
                            c->cfg.size, c->d_stamps, c->d_counts, c->d_counters);
     return hipGetLastError();
 }

@@ -63,6 +63,37 @@ def test_bresenham_exhaustive():
     assert (orc.bresenham(7, -3, 12, -1) - [7, -3] == orc.bresenham(0, 0, 5, 2)).all()
 
 
+def test_bresenham_major_axis_property():
+    """The raster kernel walks rays in major/minor form (csrc/raycast_tiled.hip): k = max(dx, dy) free
+    cells then the end cell, ONE minor-axis test per cell (E < (dmaj + 1) >> 1).  That restatement of
+    dual_bot_mapper.py:158-179 is checked here against the oracle's walk for every offset the tile
+    path can see (|d| < 64) and beyond."""
+    D = 96
+    dys, dxs = np.meshgrid(np.arange(-D, D + 1), np.arange(-D, D + 1), indexing="ij")
+    dxs, dys = dxs.ravel(), dys.ravel()
+    adx, ady = np.abs(dxs), np.abs(dys)
+    sx, sy = np.where(dxs > 0, 1, -1), np.where(dys > 0, 1, -1)
+    xmaj = adx >= ady
+    dmaj, dmin = np.where(xmaj, adx, ady), np.where(xmaj, ady, adx)
+    E, H = dmaj - dmin, (dmaj + 1) >> 1
+    x, y = np.zeros_like(dxs), np.zeros_like(dys)
+    walk = np.zeros((dxs.size, D + 1, 2), dtype=np.int64)
+    for it in range(D + 1):
+        live = it <= dmaj
+        walk[live, it, 0], walk[live, it, 1] = x[live], y[live]
+        minor = E < H
+        E = E + np.where(minor, dmaj - dmin, -dmin)
+        x = x + np.where(xmaj | minor, sx, 0)
+        y = y + np.where(~xmaj | minor, sy, 0)
+    for i in range(0, dxs.size, 7):          # every 7th offset: 5.3 k oracle walks
+        want = orc.bresenham(0, 0, int(dxs[i]), int(dys[i]))
+        n = int(dmaj[i]) + 1
+        assert want.shape[0] == n and (walk[i, :n] == want).all(), (dxs[i], dys[i])
+        assert (want[-1] == [dxs[i], dys[i]]).all()
+        major = want[:, 0] if xmaj[i] else want[:, 1]
+        assert (np.abs(np.diff(major)) == 1).all() or n == 1
+
+
 def test_update_ray_cases():
     t = load("update_ray_cases")
     size, res, ox, oy = t["cfg"]
