@@ -371,7 +371,7 @@ qs_raster_kernel(QtWorkspace ws, int size, unsigned int *__restrict__ stamps,
             const unsigned int j = j0 + slot;
             // Walk state in major/minor form.  The walk of dual_bot_mapper.py:166-178 advances its
             // major axis in EVERY iteration and reaches (x1, y1) after exactly max(dx, dy) of them
-            // (tests/test_oracle_golden.py::test_bresenham_major_axis_property), so with
+            // (property-tested on the CPU: tests/, test_bresenham_major_axis_property), so with
             //   E = err (x-major, dx >= dy) or -err (y-major)
             // the pair of tests `e2 > -dy`, `e2 < dx` (:172-177) is ONE test per cell: the minor axis
             // steps iff 2 E < dmaj, i.e. E < (dmaj + 1) >> 1, and E += minor ? dmaj - dmin : -dmin.
