@@ -198,7 +198,7 @@ extern "C" int qs_create(const qs_config *cfg, qs_ctx **out)
     c->win = cfg->min_poses_between < 1 ? 1 : (cfg->min_poses_between > QS_WIN_MAX ? QS_WIN_MAX : cfg->min_poses_between);
     c->r2_threshold = r2_threshold_for(cfg->closure_radius);
     c->cells = (size_t)cfg->size * cfg->size;
-    c->geom = QsGeom{cfg->size, cfg->res, cfg->ox, cfg->oy, cfg->min_dist, cfg->max_dist};
+    c->geom = QsGeom{cfg->size, cfg->res, cfg->ox, cfg->oy, cfg->min_dist, cfg->max_dist, 1.0 / cfg->res};
     {   // landmark buckets: edge a hair above the closure radius, so that two points closer than the
         // radius are never two buckets apart whatever the rounding of (v - b0) / cell
         const double cell = cfg->closure_radius > 0 ? cfg->closure_radius * (1.0 + 1e-9) : 1.0;
@@ -534,6 +534,7 @@ extern "C" int qs_last_hits(qs_ctx *c, double *xy, uint8_t *valid, size_t n)
     if (n == 0) return QS_OK;
     HIPCHK(c, hipSetDevice(c->device));
     std::vector<uint8_t> acc(n);
+    HIPCHK(c, qs_launch_hits(c, n));
     HIPCHK(c, hipMemcpyAsync(acc.data(), c->b.accept, n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(xy, c->b.hit, 4 * n * sizeof(double2), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(valid, c->b.hit_valid, 4 * n, hipMemcpyDeviceToHost, c->stream));

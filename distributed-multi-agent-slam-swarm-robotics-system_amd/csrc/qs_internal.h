@@ -82,6 +82,7 @@ struct QsGeom {
     int size;
     double res, ox, oy;
     double min_dist, max_dist;
+    double inv_res;          // 1.0 / res: screens world_to_grid quotients, never decides one (raycast_common.h)
 };
 
 // ---- decoded batch (SoA, one slot per datagram of the batch) -----------------------------
@@ -94,8 +95,8 @@ struct QsBatch {
     float4 *dist;            // front, left, back, right (metres)
     int *enc;                // encoder ticks
     double *rx, *ry;         // pose after drift correction (:855-857), written by the SLAM stage
-    double2 *hit;            // 4 per datagram: ray end points (valid hits only meaningful)
-    unsigned char *hit_valid;
+    double2 *hit;            // 4 per datagram: ray end points, filled on request (qs_launch_hits)
+    unsigned char *hit_valid; // MIN < d <= MAX per ray (:888); the tiled raycast writes it on the ingest path
 };
 
 struct qs_ctx {
@@ -163,6 +164,7 @@ hipError_t qs_launch_slam(qs_ctx *c, size_t n, bool raw_pose = false);
 int qs_slam_blocks(size_t n);
 // raycast.hip
 hipError_t qs_launch_raycast_direct(qs_ctx *c, size_t n, uint64_t seq0);
+hipError_t qs_launch_hits(qs_ctx *c, size_t n);                 // ray end points of the resident batch (qs_last_hits)
 hipError_t qs_launch_update_rays(qs_ctx *c, const double *rx, const double *ry, const double *hx,
                                  const double *hy, const unsigned char *valid, size_t n,
                                  uint64_t seq0);

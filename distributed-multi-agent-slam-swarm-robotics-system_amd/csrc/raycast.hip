@@ -36,23 +36,15 @@ qs_raycast_direct_kernel(size_t n, QsBatch b, QsGeom geo, unsigned int *__restri
     const size_t i = r >> 2;
     const int s = (int)(r & 3);
     unsigned int my_cells = 0, my_ray = 0, my_hit = 0;
+    QsZoneAcc zacc; zacc.agent = -1; zacc.mnx = zacc.mny = zacc.mxx = zacc.mxy = 0.0;
     if (i < n && b.accept[i]) {
         const double rx = b.rx[i], ry = b.ry[i], yaw = b.yaw[i];
         const float4 d4 = b.dist[i];
         const float df = s == 0 ? d4.x : (s == 1 ? d4.y : (s == 2 ? d4.z : d4.w));
         const int agent = b.agent[i];
         QsRay ray = qs_project_ray(rx, ry, yaw, (double)df, s, geo);
-        b.hit[r] = make_double2(ray.ex, ray.ey);
-        b.hit_valid[r] = ray.valid ? 1 : 0;
-        if (s == 0) {   // paths[agent].append  :878-879
-            atomicMin(&s_zone[agent][0], qs_ord_from_double(rx)); atomicMin(&s_zone[agent][1], qs_ord_from_double(ry));
-            atomicMax(&s_zone[agent][2], qs_ord_from_double(rx)); atomicMax(&s_zone[agent][3], qs_ord_from_double(ry));
-        }
-        if (ray.valid) {  // point_clouds[agent][name].append  :892
-            atomicMin(&s_zone[agent][0], qs_ord_from_double(ray.ex)); atomicMin(&s_zone[agent][1], qs_ord_from_double(ray.ey));
-            atomicMax(&s_zone[agent][2], qs_ord_from_double(ray.ex)); atomicMax(&s_zone[agent][3], qs_ord_from_double(ray.ey));
-            my_hit = 1;
-        }
+        if (s == 0) qs_zone_add(s_zone, zacc, agent, rx, ry);                          // paths[agent].append  :878-879
+        if (ray.valid) { qs_zone_add(s_zone, zacc, agent, ray.ex, ray.ey); my_hit = 1; }  // point_clouds[..].append  :892
         my_ray = 1;
         const unsigned int key_free = (unsigned int)((ord_base + ord_stride * i + s + 1) << 1);
         QsLine ln;
@@ -74,6 +66,7 @@ qs_raycast_direct_kernel(size_t n, QsBatch b, QsGeom geo, unsigned int *__restri
         }
     }
     // block-level counters and zone flush
+    qs_zone_flush(s_zone, zacc);
     if (my_ray) atomicAdd(&s_cnt[0], my_ray);
     if (my_cells) atomicAdd(&s_cnt[1], my_cells);
     if (my_hit) atomicAdd(&s_cnt[2], my_hit);
@@ -172,5 +165,35 @@ hipError_t qs_launch_world_to_grid(qs_ctx *c, const double *w, size_t n, int axi
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(qs_world_to_grid_kernel, dim3((unsigned int)((n + 255) / 256)), dim3(256), 0, c->stream,
                        w, n, axis ? c->geom.oy : c->geom.ox, c->geom.res, out);
+    return hipGetLastError();
+}
+
+// ---- hit points of the last batch, on request ---------------------------------------------------
+// point_clouds[agent][name].append((hx, hy))  dual_bot_mapper.py:889-892.  The map update needs only
+// the grid cells of a ray, so the world-frame end points (64 B per packet) are not written on the
+// ingest path; qs_last_hits recomputes them with the same projection from the batch that is still
+// resident, which gives the same bits.
+__global__ void __launch_bounds__(RC_BLOCK)
+qs_hits_kernel(size_t n, QsBatch b, QsGeom geo)
+{
+    const size_t r = (size_t)blockIdx.x * RC_BLOCK + threadIdx.x;
+    const size_t i = r >> 2;
+    if (i >= n) return;
+    double2 h = make_double2(0.0, 0.0);
+    unsigned char v = 0;
+    if (b.accept[i]) {
+        const QsRay ray = qs_project_ray(b.rx[i], b.ry[i], b.yaw[i], (double)((const float *)b.dist)[r], (int)(r & 3), geo);
+        h = make_double2(ray.ex, ray.ey);
+        v = ray.valid ? 1 : 0;
+    }
+    b.hit[r] = h;
+    b.hit_valid[r] = v;
+}
+
+hipError_t qs_launch_hits(qs_ctx *c, size_t n)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(qs_hits_kernel, dim3((unsigned int)((4 * n + RC_BLOCK - 1) / RC_BLOCK)), dim3(RC_BLOCK), 0,
+                       c->stream, n, c->b, c->geom);
     return hipGetLastError();
 }

@@ -38,7 +38,7 @@
 #define QT_BIN_BLOCK 1024                // pass A / C workgroup
 #define QT_MAX_WG 512                    // persistent workgroups of pass A / C (2 per CU)
 #define QT_MAX_TILES 16384               // LDS histogram limit: 64 KiB (8192^2 cells)
-#define QT_NO_RAY ((int)0x80000000)
+#define QT_NO_RAY (-32768)              // x0 of "no ray": grids are <= 16384 cells wide, rays < 64 cells past an edge
 #ifndef QT_RASTER_WGS
 #define QT_RASTER_WGS 1024               // persistent raster workgroups (4 per CU)
 #endif
@@ -52,8 +52,9 @@ struct QtWorkspace {
     unsigned int *tile_count;    // [n_tiles]   records per tile
     unsigned int *tile_base;     // [n_tiles+1] exclusive scan of tile_count
     unsigned int *chunk_base;    // [n_tiles+1] exclusive scan of ceil(count / QT_CHUNK)
-    int4 *rays;                  // [4n]        absolute grid end points (x0,y0,x1,y1); x0 = QT_NO_RAY: none
-    uint4 *recs;                 // [16n]       tile records
+    uint2 *rays;                 // [4n]        absolute grid end points, i16 x 4: (x0 | y0 << 16, x1 | y1 << 16);
+                                 //             x0 = QT_NO_RAY: none
+    uint2 *recs;                 // [16n]       tile records: tile-relative end points, i8 x 4; stamp | observed-hit bit
     int tiles_x, n_tiles, nwg;
     size_t pk_per_wg;            // packets per workgroup (multiple of 64)
 };
@@ -86,46 +87,64 @@ qs_rays_kernel(size_t n, QsBatch b, QsGeom geo, QtWorkspace ws, unsigned int *__
     if (tid < 3) s_cnt[tid] = 0;
     __syncthreads();
 
-    const size_t p0 = (size_t)blockIdx.x * ws.pk_per_wg;
-    const size_t p1 = (p0 + ws.pk_per_wg < n) ? p0 + ws.pk_per_wg : n;
+    // one THREAD per ray (4 per packet): small per-thread state, so twice the waves of a
+    // thread-per-packet form fit a SIMD, and every store of the pass is a full coalesced row
+    const size_t r0 = 4 * (size_t)blockIdx.x * ws.pk_per_wg;
+    const size_t r1 = (r0 + 4 * ws.pk_per_wg < 4 * n) ? r0 + 4 * ws.pk_per_wg : 4 * n;
     unsigned int my_cells = 0, my_rays = 0, my_hits = 0;
-    for (size_t i = p0 + tid; i < p1; i += QT_BIN_BLOCK) {
-        int4 recs[4];
-        #pragma unroll
-        for (int s = 0; s < 4; s++) recs[s] = make_int4(QT_NO_RAY, 0, 0, 0);
-        if (b.accept[i]) {
-            const double rx = b.rx[i], ry = b.ry[i], yaw = b.yaw[i];
-            const float4 d4 = b.dist[i];
-            const int agent = b.agent[i];
-            const float df[4] = {d4.x, d4.y, d4.z, d4.w};
-            double mnx = rx, mxx = rx, mny = ry, mxy = ry;         // paths[agent].append  :878-879
-            #pragma unroll
-            for (int s = 0; s < 4; s++) {
-                const QsRay ray = qs_project_ray(rx, ry, yaw, (double)df[s], s, geo);
-                b.hit[4 * i + s] = make_double2(ray.ex, ray.ey);
-                b.hit_valid[4 * i + s] = ray.valid ? 1 : 0;
-                if (ray.valid) {                                   // point_clouds[agent][name].append  :892
-                    mnx = ray.ex < mnx ? ray.ex : mnx; mxx = ray.ex > mxx ? ray.ex : mxx;
-                    mny = ray.ey < mny ? ray.ey : mny; mxy = ray.ey > mxy ? ray.ey : mxy;
-                    my_hits++;
-                }
-                my_rays++;
-                QsLine ln;
-                if (!qs_line_setup(ray, rx, ry, geo, ln)) continue;
+    QsZoneAcc zacc; zacc.agent = -1; zacc.mnx = zacc.mny = zacc.mxx = zacc.mxy = 0.0;
+    // the inputs of the NEXT ray are requested before the current one is processed: a thread's rays
+    // are 256 packets apart, so every iteration would otherwise start with a full HBM round trip
+    unsigned char acc_n = 0, agent_n = 0;
+    double rx_n = 0, ry_n = 0, yaw_n = 0;
+    float df_n = 0;
+    if (r0 + tid < r1) {
+        const size_t r = r0 + tid, i = r >> 2;
+        acc_n = b.accept[i]; agent_n = b.agent[i]; rx_n = b.rx[i]; ry_n = b.ry[i]; yaw_n = b.yaw[i];
+        df_n = ((const float *)b.dist)[r];
+    }
+    for (size_t r = r0 + tid; r < r1; r += QT_BIN_BLOCK) {
+        const size_t i = r >> 2;
+        const int s = (int)(r & 3);
+        const unsigned char acc = acc_n;
+        const int agent = agent_n;
+        const double rx = rx_n, ry = ry_n, yaw = yaw_n;
+        const float df = df_n;
+        if (r + QT_BIN_BLOCK < r1) {
+            const size_t rn = r + QT_BIN_BLOCK, in = rn >> 2;
+            acc_n = b.accept[in]; agent_n = b.agent[in]; rx_n = b.rx[in]; ry_n = b.ry[in]; yaw_n = b.yaw[in];
+            df_n = ((const float *)b.dist)[rn];
+        }
+        uint2 rec = make_uint2((unsigned int)QT_NO_RAY & 0xffffu, 0u);
+        bool valid = false;
+        if (acc) {
+            const QsRay ray = qs_project_ray(rx, ry, yaw, (double)df, s, geo);
+            valid = ray.valid;
+            // compute_bounding_box over hits U path (:702-706, :930-940): exact min/max, any order
+            if (s == 0) qs_zone_add(s_zone, zacc, agent, rx, ry);                  // paths[agent].append  :878-879
+            if (valid) { qs_zone_add(s_zone, zacc, agent, ray.ex, ray.ey); my_hits++; }   // point_clouds[..].append  :892
+            my_rays++;
+            QsLine ln;
+            if (qs_line_setup(ray, rx, ry, geo, ln)) {
                 if (ln.dx < QT_TILE && ln.dy < QT_TILE) {
                     // the ray's cells lie in at most 2 x 2 tiles
                     int tx_lo, tx_hi, ty_lo, ty_hi;
                     qt_tile_range(ln.x0, ln.y0, ln.x1, ln.y1, geo.size, tx_lo, tx_hi, ty_lo, ty_hi);
-                    for (int ty = ty_lo; ty <= ty_hi; ty++)
-                        for (int tx = tx_lo; tx <= tx_hi; tx++) atomicAdd(&s_hist[ty * ws.tiles_x + tx], 1u);
-                    recs[s] = make_int4(ln.x0, ln.y0, ln.x1, ln.y1);
+                    const int t00 = ty_lo * ws.tiles_x + tx_lo;
+                    const bool wx = tx_hi > tx_lo, wy = ty_hi > ty_lo;      // dx, dy < 64: at most one boundary each
+                    atomicAdd(&s_hist[t00], 1u);
+                    if (wx) atomicAdd(&s_hist[t00 + 1], 1u);
+                    if (wy) atomicAdd(&s_hist[t00 + ws.tiles_x], 1u);
+                    if (wx && wy) atomicAdd(&s_hist[t00 + ws.tiles_x + 1], 1u);
+                    rec = make_uint2(((unsigned int)ln.x0 & 0xffffu) | ((unsigned int)ln.y0 << 16),
+                                     ((unsigned int)ln.x1 & 0xffffu) | ((unsigned int)ln.y1 << 16));
                 } else {
                     // long ray (fine resolution): direct global atomics, as raycast.hip
                     const unsigned int key_free = (unsigned int)((ord_base + ord_stride * i + s + 1) << 1);
                     int x = ln.x0, y = ln.y0, err = ln.dx - ln.dy;
                     for (;;) {
                         const bool last = (x == ln.x1 && y == ln.y1);
-                        if ((!last || ray.valid) && x >= 0 && x < geo.size && y >= 0 && y < geo.size) {
+                        if ((!last || valid) && x >= 0 && x < geo.size && y >= 0 && y < geo.size) {
                             const size_t c = (size_t)y * geo.size + x;
                             atomicMax(&stamps[c], key_free | (last ? 1u : 0u));
                             if (COUNTS) atomicAdd(&counts[c], last ? (1ull << 32) : 1ull);
@@ -138,13 +157,11 @@ qs_rays_kernel(size_t n, QsBatch b, QsGeom geo, QtWorkspace ws, unsigned int *__
                     }
                 }
             }
-            // compute_bounding_box over hits U path (:702-706, :930-940): exact min/max, any order
-            atomicMin(&s_zone[agent][0], qs_ord_from_double(mnx)); atomicMin(&s_zone[agent][1], qs_ord_from_double(mny));
-            atomicMax(&s_zone[agent][2], qs_ord_from_double(mxx)); atomicMax(&s_zone[agent][3], qs_ord_from_double(mxy));
         }
-        #pragma unroll
-        for (int s = 0; s < 4; s++) ws.rays[4 * i + s] = recs[s];
+        ws.rays[r] = rec;
+        b.hit_valid[r] = valid ? 1 : 0;
     }
+    qs_zone_flush(s_zone, zacc);
     if (my_rays) atomicAdd(&s_cnt[0], my_rays);
     if (my_cells) atomicAdd(&s_cnt[1], my_cells);
     if (my_hits) atomicAdd(&s_cnt[2], my_hits);
@@ -153,8 +170,12 @@ qs_rays_kernel(size_t n, QsBatch b, QsGeom geo, QtWorkspace ws, unsigned int *__
     for (int t = tid; t < ws.n_tiles; t += QT_BIN_BLOCK) row[t] = s_hist[t];
     for (int t = tid; t <= max_agent; t += QT_BIN_BLOCK) {
         if (s_zone[t][0] != QS_ORD_MIN_IDENT) {
-            atomicMin(&zone[4 * t + 0], s_zone[t][0]); atomicMin(&zone[4 * t + 1], s_zone[t][1]);
-            atomicMax(&zone[4 * t + 2], s_zone[t][2]); atomicMax(&zone[4 * t + 3], s_zone[t][3]);
+            // the session's box rarely moves: read first, serialise on the 8 words only when it does
+            const volatile unsigned long long *zg = zone + 4 * t;
+            if (s_zone[t][0] < zg[0]) atomicMin(&zone[4 * t + 0], s_zone[t][0]);
+            if (s_zone[t][1] < zg[1]) atomicMin(&zone[4 * t + 1], s_zone[t][1]);
+            if (s_zone[t][2] > zg[2]) atomicMax(&zone[4 * t + 2], s_zone[t][2]);
+            if (s_zone[t][3] > zg[3]) atomicMax(&zone[4 * t + 3], s_zone[t][3]);
         }
     }
     if (tid == 0) {
@@ -165,22 +186,43 @@ qs_rays_kernel(size_t n, QsBatch b, QsGeom geo, QtWorkspace ws, unsigned int *__
 }
 
 // ---- pass B1: per tile, exclusive scan of its table column over the workgroups -------------------
-__global__ void __launch_bounds__(256)
+// One 1024-thread workgroup per 64 tiles: thread (seg, t) owns rows [seg * R, (seg + 1) * R) of
+// tile column t (R = ceil(nwg / 16) <= 32); a wave reads one 256-byte row segment per instruction
+// and all R loads of a thread are in flight together, so the column costs one HBM round trip.  The 16
+// segment sums of a column are combined through LDS and the running offsets written back.
+#define QT_SCAN_TILES 64
+#define QT_SCAN_SEGS 16
+#define QT_SCAN_ROWS (QT_MAX_WG / QT_SCAN_SEGS)
+
+__global__ void __launch_bounds__(QT_SCAN_TILES * QT_SCAN_SEGS)
 qs_table_scan_kernel(QtWorkspace ws)
 {
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= ws.n_tiles) return;
-    unsigned int run = 0;
-    int w = 0;
-    for (; w + 8 <= ws.nwg; w += 8) {
-        unsigned int v[8];
-        #pragma unroll
-        for (int q = 0; q < 8; q++) v[q] = ws.table[(size_t)(w + q) * ws.n_tiles + t];
-        #pragma unroll
-        for (int q = 0; q < 8; q++) { ws.table[(size_t)(w + q) * ws.n_tiles + t] = run; run += v[q]; }
+    __shared__ unsigned int s_part[QT_SCAN_SEGS][QT_SCAN_TILES];
+    const int tid = threadIdx.x;
+    const int lt = tid & (QT_SCAN_TILES - 1), seg = tid >> 6;
+    const int t = blockIdx.x * QT_SCAN_TILES + lt;
+    const int R = (ws.nwg + QT_SCAN_SEGS - 1) / QT_SCAN_SEGS;
+    const int w0 = seg * R;
+    const bool live = t < ws.n_tiles;
+    unsigned int v[QT_SCAN_ROWS];
+    unsigned int sum = 0;
+    #pragma unroll
+    for (int q = 0; q < QT_SCAN_ROWS; q++) {
+        v[q] = (live && q < R && w0 + q < ws.nwg) ? ws.table[(size_t)(w0 + q) * ws.n_tiles + t] : 0u;
     }
-    for (; w < ws.nwg; w++) { const unsigned int v = ws.table[(size_t)w * ws.n_tiles + t]; ws.table[(size_t)w * ws.n_tiles + t] = run; run += v; }
-    ws.tile_count[t] = run;
+    #pragma unroll
+    for (int q = 0; q < QT_SCAN_ROWS; q++) sum += v[q];
+    s_part[seg][lt] = sum;
+    __syncthreads();
+    unsigned int run = 0, total = 0;
+    #pragma unroll
+    for (int q = 0; q < QT_SCAN_SEGS; q++) { const unsigned int p = s_part[q][lt]; if (q < seg) run += p; total += p; }
+    #pragma unroll
+    for (int q = 0; q < QT_SCAN_ROWS; q++) {
+        if (live && q < R && w0 + q < ws.nwg) ws.table[(size_t)(w0 + q) * ws.n_tiles + t] = run;
+        run += v[q];
+    }
+    if (live && seg == 0) ws.tile_count[t] = total;
 }
 
 // ---- pass B2: one workgroup, two exclusive scans over the tiles --------------------------------
@@ -224,23 +266,25 @@ qs_scatter_kernel(size_t n, QsBatch b, QtWorkspace ws, int size, unsigned long l
     const size_t r0 = 4 * (size_t)blockIdx.x * ws.pk_per_wg;
     const size_t r1 = (r0 + 4 * ws.pk_per_wg < 4 * n) ? r0 + 4 * ws.pk_per_wg : 4 * n;
     for (size_t r = r0 + tid; r < r1; r += QT_BIN_BLOCK) {
-        const int4 ray = ws.rays[r];
-        if (ray.x == QT_NO_RAY) continue;
+        const uint2 ray = ws.rays[r];
+        const int x0 = (short)(ray.x & 0xffffu), y0 = (short)(ray.x >> 16);
+        if (x0 == QT_NO_RAY) continue;
+        const int x1 = (short)(ray.y & 0xffffu), y1 = (short)(ray.y >> 16);
         int tx_lo, tx_hi, ty_lo, ty_hi;
-        qt_tile_range(ray.x, ray.y, ray.z, ray.w, size, tx_lo, tx_hi, ty_lo, ty_hi);
-        const unsigned int key_free = (unsigned int)((ord_base + ord_stride * (r >> 2) + (r & 3) + 1) << 1);
-        const unsigned int flags = b.hit_valid[r] ? 1u : 0u;
-        for (int ty = ty_lo; ty <= ty_hi; ty++)
-            for (int tx = tx_lo; tx <= tx_hi; tx++) {
-                const unsigned int slot = atomicAdd(&s_cur[ty * ws.tiles_x + tx], 1u);
-                const int ox = tx << QT_TILE_SHIFT, oy = ty << QT_TILE_SHIFT;   // tile origin
-                uint4 rec;
-                rec.x = ((unsigned int)(ray.x - ox) & 0xffffu) | ((unsigned int)(ray.y - oy) << 16);
-                rec.y = ((unsigned int)(ray.z - ox) & 0xffffu) | ((unsigned int)(ray.w - oy) << 16);
-                rec.z = key_free;
-                rec.w = flags;
-                ws.recs[slot] = rec;
-            }
+        qt_tile_range(x0, y0, x1, y1, size, tx_lo, tx_hi, ty_lo, ty_hi);
+        // stamp of the ray's free cells; bit 0 (the occupied bit of a cell stamp) carries "the end
+        // cell was observed" into the raster pass
+        const unsigned int key = (unsigned int)((ord_base + ord_stride * (r >> 2) + (r & 3) + 1) << 1) | (b.hit_valid[r] ? 1u : 0u);
+        // dx, dy < 64: the tile box is 1 x 1, 2 x 1, 1 x 2 or 2 x 2 (same enumeration as pass A)
+        #pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int tx = tx_lo + (q & 1), ty = ty_lo + (q >> 1);
+            if (tx > tx_hi || ty > ty_hi) continue;
+            const unsigned int slot = atomicAdd(&s_cur[ty * ws.tiles_x + tx], 1u);
+            const int ox = tx << QT_TILE_SHIFT, oy = ty << QT_TILE_SHIFT;   // tile origin: |coord - origin| < 128
+            ws.recs[slot] = make_uint2(((unsigned int)(x0 - ox) & 0xffu) | (((unsigned int)(y0 - oy) & 0xffu) << 8) |
+                                       (((unsigned int)(x1 - ox) & 0xffu) << 16) | ((unsigned int)(y1 - oy) << 24), key);
+        }
     }
 }
 
@@ -311,7 +355,7 @@ __device__ inline void qt_merge_tile(unsigned int *s_stamp, unsigned int *s_cnt,
 }
 
 template <bool COUNTS>
-__global__ void __launch_bounds__(QT_BLOCK)
+__global__ void __launch_bounds__(QT_BLOCK, 8)
 qs_raster_kernel(QtWorkspace ws, int size, unsigned int *__restrict__ stamps,
                  unsigned long long *__restrict__ counts, unsigned long long *__restrict__ counters)
 {
@@ -382,11 +426,11 @@ qs_raster_kernel(QtWorkspace ws, int size, unsigned int *__restrict__ stamps,
             unsigned int key_free = 0;
             bool wl = false;
             if (j < re) {
-                const uint4 rec = ws.recs[j];
-                const int x = (short)(rec.x & 0xffffu), x1 = (short)(rec.y & 0xffffu);
-                const int y1 = (short)(rec.y >> 16);
-                y = (short)(rec.x >> 16);
-                key_free = rec.z;
+                const uint2 rec = ws.recs[j];
+                const int x = (signed char)(rec.x & 0xffu), x1 = (signed char)((rec.x >> 16) & 0xffu);
+                const int y1 = (signed char)(rec.x >> 24);
+                y = (signed char)((rec.x >> 8) & 0xffu);
+                key_free = rec.y & ~1u;
                 const int dx = abs(x1 - x), dy = abs(y1 - y);                  // :161-162
                 const int sx4 = x < x1 ? 4 : -4, sy = y < y1 ? 1 : -1;         // :163-164 (x in bytes)
                 const bool xmaj = dx >= dy;
@@ -394,7 +438,7 @@ qs_raster_kernel(QtWorkspace ws, int size, unsigned int *__restrict__ stamps,
                 k = dmaj; E = dmaj - dmin; H = (dmaj + 1) >> 1; incA = dmaj - dmin; incB = -dmin;
                 sx_c = sx4; sx_n = xmaj ? sx4 : 0; sy_c = sy; sy_n = xmaj ? 0 : sy;
                 x4 = x << 2;
-                wl = (rec.w & 1u) && (unsigned int)x1 < (unsigned int)tw && (unsigned int)y1 < (unsigned int)th;
+                wl = (rec.y & 1u) && (unsigned int)x1 < (unsigned int)tw && (unsigned int)y1 < (unsigned int)th;
                 if (wl) {                                                      // :148-150 occupied end cell
                     const int c = y1 * QT_PITCH + x1;
                     atomicMax(&s_stamp[c], key_free | 1u);
@@ -440,7 +484,7 @@ size_t qs_tiled_workspace_bytes(const qs_ctx *c, size_t n)
 {
     const size_t n_tiles = (size_t)qt_n_tiles(c);
     return qt_align((size_t)QT_MAX_WG * n_tiles * sizeof(unsigned int)) + 3 * qt_align((n_tiles + 1) * sizeof(unsigned int)) +
-           qt_align(4 * n * sizeof(int4)) + qt_align(16 * n * sizeof(uint4));
+           qt_align(4 * n * sizeof(uint2)) + qt_align(16 * n * sizeof(uint2));
 }
 
 hipError_t qs_launch_raycast_tiled(qs_ctx *c, size_t n, uint64_t seq0)
@@ -470,8 +514,8 @@ hipError_t qs_launch_raycast_tiled(qs_ctx *c, size_t n, uint64_t seq0)
     ws.tile_count = (unsigned int *)p; p += tbytes;
     ws.tile_base = (unsigned int *)p; p += tbytes;
     ws.chunk_base = (unsigned int *)p; p += tbytes;
-    ws.rays = (int4 *)p; p += qt_align(4 * c->cap_batch * sizeof(int4));
-    ws.recs = (uint4 *)p;
+    ws.rays = (uint2 *)p; p += qt_align(4 * c->cap_batch * sizeof(uint2));
+    ws.recs = (uint2 *)p;
 
     const unsigned long long ord_base = 4ull * (seq0 - c->epoch_base);
     const unsigned long long ord_stride = 4ull * (unsigned long long)(c->cfg.seq_stride > 0 ? c->cfg.seq_stride : 1);
@@ -495,7 +539,8 @@ hipError_t qs_launch_raycast_tiled(qs_ctx *c, size_t n, uint64_t seq0)
         hipLaunchKernelGGL(qs_rays_kernel<false>, dim3(ws.nwg), dim3(QT_BIN_BLOCK), lds, c->stream, n, c->b, c->geom, ws,
                            c->d_stamps, c->d_counts, ord_base, ord_stride, c->d_zone, c->cfg.max_agent, c->d_counters);
     }
-    hipLaunchKernelGGL(qs_table_scan_kernel, dim3((ws.n_tiles + 255) / 256), dim3(256), 0, c->stream, ws);
+    hipLaunchKernelGGL(qs_table_scan_kernel, dim3((ws.n_tiles + QT_SCAN_TILES - 1) / QT_SCAN_TILES),
+                       dim3(QT_SCAN_TILES * QT_SCAN_SEGS), 0, c->stream, ws);
     hipLaunchKernelGGL(qs_tile_scan_kernel, dim3(1), dim3(1024), 0, c->stream, ws);
     hipLaunchKernelGGL(qs_scatter_kernel, dim3(ws.nwg), dim3(QT_BIN_BLOCK), lds, c->stream, n, c->b, ws,
                        c->cfg.size, ord_base, ord_stride);
