@@ -22,13 +22,10 @@ qs_raycast_direct_kernel(size_t n, QsBatch b, QsGeom geo, unsigned int *__restri
                          unsigned long long ord_stride, unsigned long long *__restrict__ zone, int max_agent,
                          unsigned long long *__restrict__ counters)
 {
-    __shared__ unsigned long long s_zone[QS_MAX_AGENT + 1][4];
+    __shared__ double s_zone[QS_MAX_AGENT + 1][4];
     __shared__ unsigned int s_cnt[3];
     const int tid = threadIdx.x;
-    for (int t = tid; t <= max_agent; t += RC_BLOCK) {
-        s_zone[t][0] = QS_ORD_MIN_IDENT; s_zone[t][1] = QS_ORD_MIN_IDENT;
-        s_zone[t][2] = QS_ORD_MAX_IDENT; s_zone[t][3] = QS_ORD_MAX_IDENT;
-    }
+    for (int t = tid; t <= max_agent; t += RC_BLOCK) QS_ZONE_LDS_INIT(s_zone, t);
     if (tid < 3) s_cnt[tid] = 0;
     __syncthreads();
 
@@ -36,15 +33,15 @@ qs_raycast_direct_kernel(size_t n, QsBatch b, QsGeom geo, unsigned int *__restri
     const size_t i = r >> 2;
     const int s = (int)(r & 3);
     unsigned int my_cells = 0, my_ray = 0, my_hit = 0;
-    QsZoneAcc zacc; zacc.agent = -1; zacc.mnx = zacc.mny = zacc.mxx = zacc.mxy = 0.0;
     if (i < n && b.accept[i]) {
         const double rx = b.rx[i], ry = b.ry[i], yaw = b.yaw[i];
         const float4 d4 = b.dist[i];
         const float df = s == 0 ? d4.x : (s == 1 ? d4.y : (s == 2 ? d4.z : d4.w));
         const int agent = b.agent[i];
         QsRay ray = qs_project_ray(rx, ry, yaw, (double)df, s, geo);
-        if (s == 0) qs_zone_add(s_zone, zacc, agent, rx, ry);                          // paths[agent].append  :878-879
-        if (ray.valid) { qs_zone_add(s_zone, zacc, agent, ray.ex, ray.ey); my_hit = 1; }  // point_clouds[..].append  :892
+        if (s == 0) qs_zone_point(s_zone, agent, rx, ry);                          // paths[agent].append  :878-879
+        if (ray.valid) qs_zone_point(s_zone, agent, ray.ex, ray.ey);               // point_clouds[..].append  :892
+        my_hit = ray.valid ? 1u : 0u;
         my_ray = 1;
         const unsigned int key_free = (unsigned int)((ord_base + ord_stride * i + s + 1) << 1);
         QsLine ln;
@@ -66,17 +63,11 @@ qs_raycast_direct_kernel(size_t n, QsBatch b, QsGeom geo, unsigned int *__restri
         }
     }
     // block-level counters and zone flush
-    qs_zone_flush(s_zone, zacc);
     if (my_ray) atomicAdd(&s_cnt[0], my_ray);
     if (my_cells) atomicAdd(&s_cnt[1], my_cells);
     if (my_hit) atomicAdd(&s_cnt[2], my_hit);
     __syncthreads();
-    for (int t = tid; t <= max_agent; t += RC_BLOCK) {
-        if (s_zone[t][0] != QS_ORD_MIN_IDENT) {
-            atomicMin(&zone[4 * t + 0], s_zone[t][0]); atomicMin(&zone[4 * t + 1], s_zone[t][1]);
-            atomicMax(&zone[4 * t + 2], s_zone[t][2]); atomicMax(&zone[4 * t + 3], s_zone[t][3]);
-        }
-    }
+    for (int t = tid; t <= max_agent; t += RC_BLOCK) qs_zone_commit(s_zone, t, zone);
     if (tid == 0) {
         if (s_cnt[0]) atomicAdd(&counters[QS_CNT_RAYS], (unsigned long long)s_cnt[0]);
         if (s_cnt[1]) atomicAdd(&counters[QS_CNT_CELLS], (unsigned long long)s_cnt[1]);

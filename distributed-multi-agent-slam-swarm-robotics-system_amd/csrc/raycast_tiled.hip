@@ -35,8 +35,12 @@
 #ifndef QT_BLOCK
 #define QT_BLOCK 512                     // raster workgroup: 8 waves share one 32 KiB LDS tile (A/B: 256 -> 512 threads = -5..-18 % stage time)
 #endif
+#ifndef QT_BIN_BLOCK
 #define QT_BIN_BLOCK 1024                // pass A / C workgroup
+#endif
+#ifndef QT_MAX_WG
 #define QT_MAX_WG 512                    // persistent workgroups of pass A / C (2 per CU)
+#endif
 #define QT_MAX_TILES 16384               // LDS histogram limit: 64 KiB (8192^2 cells)
 #define QT_NO_RAY (-32768)              // x0 of "no ray": grids are <= 16384 cells wide, rays < 64 cells past an edge
 #ifndef QT_RASTER_WGS
@@ -76,14 +80,11 @@ qs_rays_kernel(size_t n, QsBatch b, QsGeom geo, QtWorkspace ws, unsigned int *__
                unsigned long long *__restrict__ zone, int max_agent, unsigned long long *__restrict__ counters)
 {
     extern __shared__ unsigned int s_hist[];                       // [n_tiles]
-    __shared__ unsigned long long s_zone[QS_MAX_AGENT + 1][4];
+    __shared__ double s_zone[QS_MAX_AGENT + 1][4];
     __shared__ unsigned int s_cnt[3];
     const int tid = threadIdx.x;
     for (int t = tid; t < ws.n_tiles; t += QT_BIN_BLOCK) s_hist[t] = 0;
-    for (int t = tid; t <= max_agent; t += QT_BIN_BLOCK) {
-        s_zone[t][0] = QS_ORD_MIN_IDENT; s_zone[t][1] = QS_ORD_MIN_IDENT;
-        s_zone[t][2] = QS_ORD_MAX_IDENT; s_zone[t][3] = QS_ORD_MAX_IDENT;
-    }
+    for (int t = tid; t <= max_agent; t += QT_BIN_BLOCK) QS_ZONE_LDS_INIT(s_zone, t);
     if (tid < 3) s_cnt[tid] = 0;
     __syncthreads();
 
@@ -92,7 +93,6 @@ qs_rays_kernel(size_t n, QsBatch b, QsGeom geo, QtWorkspace ws, unsigned int *__
     const size_t r0 = 4 * (size_t)blockIdx.x * ws.pk_per_wg;
     const size_t r1 = (r0 + 4 * ws.pk_per_wg < 4 * n) ? r0 + 4 * ws.pk_per_wg : 4 * n;
     unsigned int my_cells = 0, my_rays = 0, my_hits = 0;
-    QsZoneAcc zacc; zacc.agent = -1; zacc.mnx = zacc.mny = zacc.mxx = zacc.mxy = 0.0;
     // the inputs of the NEXT ray are requested before the current one is processed: a thread's rays
     // are 256 packets apart, so every iteration would otherwise start with a full HBM round trip
     unsigned char acc_n = 0, agent_n = 0;
@@ -121,8 +121,9 @@ qs_rays_kernel(size_t n, QsBatch b, QsGeom geo, QtWorkspace ws, unsigned int *__
             const QsRay ray = qs_project_ray(rx, ry, yaw, (double)df, s, geo);
             valid = ray.valid;
             // compute_bounding_box over hits U path (:702-706, :930-940): exact min/max, any order
-            if (s == 0) qs_zone_add(s_zone, zacc, agent, rx, ry);                  // paths[agent].append  :878-879
-            if (valid) { qs_zone_add(s_zone, zacc, agent, ray.ex, ray.ey); my_hits++; }   // point_clouds[..].append  :892
+            if (s == 0) qs_zone_point(s_zone, agent, rx, ry);                // paths[agent].append  :878-879
+            if (valid) qs_zone_point(s_zone, agent, ray.ex, ray.ey);         // point_clouds[..].append  :892
+            my_hits += valid ? 1u : 0u;
             my_rays++;
             QsLine ln;
             if (qs_line_setup(ray, rx, ry, geo, ln)) {
@@ -161,23 +162,13 @@ qs_rays_kernel(size_t n, QsBatch b, QsGeom geo, QtWorkspace ws, unsigned int *__
         ws.rays[r] = rec;
         b.hit_valid[r] = valid ? 1 : 0;
     }
-    qs_zone_flush(s_zone, zacc);
     if (my_rays) atomicAdd(&s_cnt[0], my_rays);
     if (my_cells) atomicAdd(&s_cnt[1], my_cells);
     if (my_hits) atomicAdd(&s_cnt[2], my_hits);
     __syncthreads();
     unsigned int *row = ws.table + (size_t)blockIdx.x * ws.n_tiles;
     for (int t = tid; t < ws.n_tiles; t += QT_BIN_BLOCK) row[t] = s_hist[t];
-    for (int t = tid; t <= max_agent; t += QT_BIN_BLOCK) {
-        if (s_zone[t][0] != QS_ORD_MIN_IDENT) {
-            // the session's box rarely moves: read first, serialise on the 8 words only when it does
-            const volatile unsigned long long *zg = zone + 4 * t;
-            if (s_zone[t][0] < zg[0]) atomicMin(&zone[4 * t + 0], s_zone[t][0]);
-            if (s_zone[t][1] < zg[1]) atomicMin(&zone[4 * t + 1], s_zone[t][1]);
-            if (s_zone[t][2] > zg[2]) atomicMax(&zone[4 * t + 2], s_zone[t][2]);
-            if (s_zone[t][3] > zg[3]) atomicMax(&zone[4 * t + 3], s_zone[t][3]);
-        }
-    }
+    for (int t = tid; t <= max_agent; t += QT_BIN_BLOCK) qs_zone_commit(s_zone, t, zone);
     if (tid == 0) {
         if (s_cnt[0]) atomicAdd(&counters[QS_CNT_RAYS], (unsigned long long)s_cnt[0]);
         if (s_cnt[1]) atomicAdd(&counters[QS_CNT_CELLS], (unsigned long long)s_cnt[1]);
@@ -410,7 +401,7 @@ qs_raster_kernel(QtWorkspace ws, int size, unsigned int *__restrict__ stamps,
         const unsigned int re = min(rb + QT_CHUNK, ws.tile_base[tile] + ws.tile_count[tile]);
         const int tx0 = (tile % ws.tiles_x) << QT_TILE_SHIFT, ty0 = (tile / ws.tiles_x) << QT_TILE_SHIFT;
         const int tw = min(QT_TILE, size - tx0), th = min(QT_TILE, size - ty0);
-        const unsigned int tw4 = 4u * (unsigned int)tw;
+        const unsigned int tw4 = 4u * (unsigned int)tw, tha = 4u * QT_PITCH * (unsigned int)th;
         for (unsigned int j0 = rb; j0 < re; j0 += QT_BLOCK) {
             const unsigned int j = j0 + slot;
             // Walk state in major/minor form.  The walk of dual_bot_mapper.py:166-178 advances its
@@ -422,22 +413,23 @@ qs_raster_kernel(QtWorkspace ws, int size, unsigned int *__restrict__ stamps,
             // The last cell (x1, y1) is the only one that can be marked occupied (:150): it is written
             // before the loop, and `x == x1 and y == y1` (:169) becomes a countdown over the
             // k = max(dx, dy) free cells.
-            int x4 = 0, y = 0, k = 0, E = 0, H = 0, incA = 0, incB = 0, sx_c = 0, sx_n = 0, sy_c = 0, sy_n = 0;
+            // x4 = 4 x and ya = 4 QT_PITCH y: the cell's LDS byte offset is their sum
+            int x4 = 0, ya = 0, k = 0, E = 0, H = 0, incA = 0, incB = 0, sx_c = 0, sx_n = 0, sy_c = 0, sy_n = 0;
             unsigned int key_free = 0;
             bool wl = false;
             if (j < re) {
                 const uint2 rec = ws.recs[j];
                 const int x = (signed char)(rec.x & 0xffu), x1 = (signed char)((rec.x >> 16) & 0xffu);
                 const int y1 = (signed char)(rec.x >> 24);
-                y = (signed char)((rec.x >> 8) & 0xffu);
+                const int y = (signed char)((rec.x >> 8) & 0xffu);
                 key_free = rec.y & ~1u;
                 const int dx = abs(x1 - x), dy = abs(y1 - y);                  // :161-162
-                const int sx4 = x < x1 ? 4 : -4, sy = y < y1 ? 1 : -1;         // :163-164 (x in bytes)
+                const int sx4 = x < x1 ? 4 : -4, sy = y < y1 ? 4 * QT_PITCH : -4 * QT_PITCH;   // :163-164, in bytes
                 const bool xmaj = dx >= dy;
                 const int dmaj = xmaj ? dx : dy, dmin = xmaj ? dy : dx;
                 k = dmaj; E = dmaj - dmin; H = (dmaj + 1) >> 1; incA = dmaj - dmin; incB = -dmin;
                 sx_c = sx4; sx_n = xmaj ? sx4 : 0; sy_c = sy; sy_n = xmaj ? 0 : sy;
-                x4 = x << 2;
+                x4 = x << 2; ya = y * (4 * QT_PITCH);
                 wl = (rec.y & 1u) && (unsigned int)x1 < (unsigned int)tw && (unsigned int)y1 < (unsigned int)th;
                 if (wl) {                                                      // :148-150 occupied end cell
                     const int c = y1 * QT_PITCH + x1;
@@ -447,15 +439,15 @@ qs_raster_kernel(QtWorkspace ws, int size, unsigned int *__restrict__ stamps,
             }
             if (!COUNTS) wave_cells += (unsigned int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(wl));
             for (int it = 0; __any(it < k); it++) {                            // :152-156 free cells
-                const bool w = it < k && (unsigned int)x4 < tw4 && (unsigned int)y < (unsigned int)th;
-                const int a = w ? y * (4 * QT_PITCH) + x4 : scratch4;
+                const bool w = it < k && (unsigned int)x4 < tw4 && (unsigned int)ya < tha;
+                const int a = w ? ya + x4 : scratch4;
                 atomicMax((unsigned int *)((char *)s_stamp + a), key_free);
                 if (COUNTS) atomicAdd((unsigned int *)((char *)s_cnt + a), 1u);
                 if (!COUNTS) wave_cells += (unsigned int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(w));
                 const bool minor = E < H;
                 E += minor ? incA : incB;
                 x4 += minor ? sx_c : sx_n;
-                y += minor ? sy_c : sy_n;
+                ya += minor ? sy_c : sy_n;
             }
         }
     }
