@@ -266,7 +266,7 @@ extern "C" int qs_destroy(qs_ctx *c)
     free_batch(c);
     hipFree(c->d_stamps); hipFree(c->d_counts); hipFree(c->d_offset); hipFree(c->d_drift);
     hipFree(c->d_last_closure); hipFree(c->d_zone); hipFree(c->d_counters); hipFree(c->d_graph_batch);
-    hipFree(c->d_ekf); hipFree(c->d_ekf_prev); hipFree(c->d_graphs); hipFree(c->d_pkts); hipFree(c->d_lens);
+    hipFree(c->d_ekf); hipFree(c->d_ekf_prev); hipFree(c->d_ekf_ws); hipFree(c->d_graphs); hipFree(c->d_pkts); hipFree(c->d_lens);
     hipFree(c->d_time); hipFree(c->d_bin_ws); hipFree(c->d_frontier_ws);
     for (auto &p : c->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (auto e : c->ev_pool) hipEventDestroy(e);
@@ -452,7 +452,8 @@ static int ingest_device(qs_ctx *c, const uint8_t *d_pkts, size_t n, size_t stri
         }
         HIPCHK(c, hipEventRecord(c->ev_decoded, c->stream));
         HIPCHK(c, hipStreamWaitEvent(c->ekf_stream, c->ev_decoded, 0));
-        { StageTimer t(c, QS_STAGE_EKF, c->ekf_stream); HIPCHK(c, qs_launch_ekf_ingest(c, n, d_time, c->ekf_stream)); t.stop(); }
+        { StageTimer t(c, QS_STAGE_EKF, c->ekf_stream); HIPCHK(c, n >= QS_EKF_SCAN_MIN_BATCH ? qs_launch_ekf_scan(c, n, d_time, c->ekf_stream)
+                                                   : qs_launch_ekf_ingest(c, n, d_time, c->ekf_stream)); t.stop(); }
         HIPCHK(c, hipEventRecord(c->ev_ekf_done, c->ekf_stream));
     }
     { StageTimer t(c, QS_STAGE_SLAM); HIPCHK(c, qs_launch_slam(c, n)); t.stop(); }

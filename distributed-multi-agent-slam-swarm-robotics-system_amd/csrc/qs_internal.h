@@ -142,6 +142,7 @@ struct qs_ctx {
     // tile-binned raycast workspace
     void *d_bin_ws = nullptr; size_t bin_ws_bytes = 0;
     void *d_frontier_ws = nullptr;               // frontier labelling workspace (allocated on first use)
+    void *d_ekf_ws = nullptr; size_t ekf_ws_bytes = 0;   // parallel-in-time EKF workspace (ekf_scan.hip)
 
     uint64_t next_seq = 0, epoch_base = 0, n_rebases = 0;
 
@@ -202,5 +203,8 @@ hipError_t qs_launch_voxel_keys(qs_ctx *c, const double2 *pts, size_t n, double 
                                 unsigned long long *keys);
 // ekf.hip
 hipError_t qs_launch_ekf_ingest(qs_ctx *c, size_t n, const double *d_time, hipStream_t st);
+// ekf_scan.hip: the same filter over a large batch, parallel in time
+#define QS_EKF_SCAN_MIN_BATCH 4096
+hipError_t qs_launch_ekf_scan(qs_ctx *c, size_t n, const double *d_time, hipStream_t st);
 hipError_t qs_launch_ekf_step(qs_ctx *c, const int *d_bots, const double *d_omega, const double *d_t,
                               const double *d_zv, const double *d_zo, size_t n, int do_update);

@@ -4,6 +4,7 @@
 Bar: integer/byte/index results bit-exact; float pose / drift / correction / zone values within
 1e-5 (north_star); here they are in fact expected to agree to ~1e-12."""
 import hashlib
+import importlib
 import os
 import struct
 
@@ -194,6 +195,64 @@ def test_ekf_ingest_matches_oracle(pkg):
         for b in (1, 2):
             x, P = m.ekf_state(b)
             assert np.abs(x - ek.state(b)).max() < 1e-9 and np.abs(P - ek.cov(b)).max() < 1e-9
+
+
+def _ekf_close(m, o, bots, rtol=1e-9):
+    for b in bots:
+        x, P = m.ekf_state(b)
+        xo, Po = o.ekf_state(b)
+        assert np.abs(x - xo).max() <= rtol * max(1.0, np.abs(xo).max()), (b, x, xo)
+        assert np.abs(P - Po).max() <= rtol * max(1.0, np.abs(Po).max()), b
+
+
+@pytest.mark.gpu
+def test_ekf_parallel_in_time_long_streams(pkg):
+    """csrc/ekf_scan.hip (batches >= 4096 packets): chunked, parallel-in-time form of the filter against the
+    sequential CPU restatement over many chunks, several batches (state carried in between, including a
+    switch between the serial small-batch kernel and the scan), nominal and irregular time stamps (zero and
+    negative steps skip the predict, ekf.cpp:28-29).  Agreement is to rounding, not bit for bit: 1e-9
+    relative here, north_star's bar is 1e-5."""
+    replay = importlib.import_module(pkg.__name__ + ".replay")
+    session, _ = replay.telemetry_csv_to_packets()
+    n = 150_000
+    stream = replay.cycle_stream(session, n)
+    cfg = dict(size=512, resolution=0.05, origin_x=-12.8, origin_y=-12.8, separation=5.0)
+    rng = np.random.default_rng(11)
+    irregular = np.cumsum(rng.choice([0.05, 0.02, 0.0, -0.01, 0.3], size=n, p=[.7, .1, .08, .04, .08])) + 100.0
+    for times in (None, irregular):
+        o = orc.OracleMapper(512, 0.05, -12.8, -12.8, separation=5.0)
+        o.enable_ekf(0.0107)
+        o.feed_stream(stream, None, times)
+        # one batch
+        with pkg.QuasarMapper(**cfg, enable_ekf=True) as m:
+            m.ingest_array(stream, recv_time=times)
+            _ekf_close(m, o, (1, 2))
+            assert m.counters()["ekf_wrap_clamp"] == 0
+        # ragged batches: scan, serial (< 4096), scan, ...
+        with pkg.QuasarMapper(**cfg, enable_ekf=True) as m:
+            lo = 0
+            for size in (5000, 100, 70_000, 3, 4096, 1, 60_000, n):
+                hi = min(lo + size, n)
+                m.ingest_array(stream[lo:hi], recv_time=None if times is None else times[lo:hi])
+                lo = hi
+                if lo == n:
+                    break
+            _ekf_close(m, o, (1, 2))
+
+
+@pytest.mark.gpu
+def test_ekf_parallel_in_time_many_bots(pkg):
+    """64 bots (1 to 3 chunks each, ragged) through the scan form against the sequential restatement."""
+    replay = importlib.import_module(pkg.__name__ + ".replay")
+    session, _ = replay.telemetry_csv_to_packets()
+    n = 100_000
+    stream = replay.multi_bot_stream(session, 64, n)
+    o = orc.OracleMapper(4096, 0.05, -102.4, -102.4, separation=0.0, max_agent=64, bots_per_graph=2)
+    o.enable_ekf(0.0107)
+    o.feed_stream(stream)
+    with pkg.QuasarMapper(4096, 0.05, -102.4, -102.4, max_agent=64, bots_per_graph=2, enable_ekf=True) as m:
+        m.ingest_array(stream)
+        _ekf_close(m, o, range(1, 65))
 
 
 def test_ekf_object_api_hand_derived(pkg):
