@@ -89,7 +89,9 @@ int qs_ingest_device(qs_ctx *ctx, const uint8_t *d_pkts, size_t n, size_t stride
 /* per record of the LAST ingest: accepted flag and pose after offset+drift (:850-857) */
 int qs_last_batch(qs_ctx *ctx, uint8_t *accepted, double *pose_xyyaw /* n x 3 */, size_t n);
 /* valid hit points of the LAST ingest (point_clouds[agent][sensor].append, :892):
- * 4 slots per record in sensor order front,left,back,right; valid[i*4+s] marks used slots */
+ * 4 slots per record in sensor order front,left,back,right; valid[i*4+s] marks used slots.
+ * Computed on request from the batch that is still resident (one extra kernel): the map update itself
+ * only needs the rays' grid cells. */
 int qs_last_hits(qs_ctx *ctx, double *xy /* n x 4 x 2 */, uint8_t *valid /* n x 4 */, size_t n);
 
 /* ---- OccupancyGrid object API ----------------------------------------------------------
@@ -172,6 +174,10 @@ int qs_frontier_cells(qs_ctx *ctx, int32_t *xy, size_t cap, size_t *n_out);
 int qs_frontier_clusters(qs_ctx *ctx, int32_t min_cluster, int64_t *stats5, size_t cap, size_t *n_out);
 
 /* ---- EKF  AgentFirmware_Bot1/ekf.cpp:5-92 ---------------------------------------------- */
+/* On ingest (qs_config.enable_ekf) the filter of every bot runs over the batch: batches of >= 4096
+ * packets in a parallel-in-time form that agrees with the step-by-step filter to rounding (~1e-12
+ * relative), smaller ones step by step.  QS_CNT_EKF_WRAP_CLAMP counts chunks whose heading-wrap count
+ * had to be clamped (a sign of absurd inputs; 0 on every stream seen). */
 /* batched over bots: for k in 0..n: predict(omega_m[k], t[k]) then update(z_v[k], z_omega[k])
  * on bot_ids[k] (each bot at most once per call); do_update == 0: predict only */
 int qs_ekf_init(qs_ctx *ctx, int32_t bot, double t, const double x0[6]);
