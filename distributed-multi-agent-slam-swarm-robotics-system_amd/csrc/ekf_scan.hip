@@ -3,7 +3,7 @@
 //
 // ekf.hip walks a bot's packets one filter step at a time: a strict recurrence, ~0.75 us per step
 // on a lone wave, 0.39 s for the 2-bot 1 M-packet batch -- 1000x the rest of the ingest.  This file
-// computes the same filter with the recurrence cut into chunks of ES_CHUNK steps that are processed
+// computes the same filter with the recurrence cut into chunks of 128..1024 steps that are processed
 // concurrently.  What makes that possible is the structure of this particular filter:
 //
 //   state  [x, y | theta, v, omega, bias];   measurement = [v, omega]
@@ -32,7 +32,8 @@
 // serial kernel of ekf.hip (lower latency for a handful of packets).
 #include "qs_internal.h"
 
-#define ES_CHUNK 1024            // filter steps per chunk
+#define ES_CHUNK_MIN 128          // filter steps per chunk: chosen per launch so that a bot's share of the
+#define ES_CHUNK_MAX 1024         // batch is ~256 chunks (E2 / E4 walk a bot's chunks one after the other)
 #define ES_PI 3.14159265358979323846
 #define ES_TWO_PI 6.28318530717958647692
 
@@ -47,7 +48,8 @@ struct EsAgg2 { double L[16], N[8], m[4], q[2], W[16], U[8], V[4]; int wrap_c, w
 struct EsWs {
     unsigned int *count;         // [256]   accepted records per bot
     unsigned int *base;          // [257]   exclusive prefix of count
-    unsigned int *chunk_base;    // [257]   exclusive prefix of ceil(count / ES_CHUNK)
+    unsigned int chunk;          //         filter steps per chunk of this launch
+    unsigned int *chunk_base;    // [257]   exclusive prefix of ceil(count / chunk)
     unsigned int *idx;           // [n]     packet index of every accepted record, bot-major
     EsRec *rec;                  // [n]
     unsigned long long *cmax;    // [chunks] max t over the chunk's init / step records (ordered key), 0 = none
@@ -101,7 +103,7 @@ es_plan_kernel(EsWs ws, int max_agent)
     __shared__ unsigned int s_a[256], s_c[256];
     const int a = threadIdx.x;
     const unsigned int cnt = (a >= 1 && a <= max_agent) ? ws.count[a] : 0u;
-    const unsigned int chk = (cnt + ES_CHUNK - 1) / ES_CHUNK;
+    const unsigned int chk = (cnt + ws.chunk - 1) / ws.chunk;
     s_a[a] = cnt; s_c[a] = chk;
     __syncthreads();
     for (int off = 1; off < 256; off <<= 1) {
@@ -202,7 +204,7 @@ es_wire_kernel(size_t n, QsBatch b, const double *__restrict__ recv_time, double
         }
     }
     ws.rec[j] = r;
-    if (r.kind != 2) atomicMax(&ws.cmax[ws.chunk_base[bot] + (j - j0) / ES_CHUNK], qs_ord_from_double(t));
+    if (r.kind != 2) atomicMax(&ws.cmax[ws.chunk_base[bot] + (j - j0) / ws.chunk], qs_ord_from_double(t));
 }
 
 // ---- E0: last predict time at every chunk start (a prefix max per bot) ---------------------------
@@ -321,8 +323,8 @@ es_agg1_kernel(EsWs ws)
     const unsigned int c = blockIdx.x * QS_WAVE + threadIdx.x;
     if (c >= ws.chunk_base[256]) return;
     const int bot = es_bot_of(ws.chunk_base, c);
-    const unsigned int j0 = ws.base[bot] + (c - ws.chunk_base[bot]) * ES_CHUNK;
-    const unsigned int j1 = min(j0 + ES_CHUNK, ws.base[bot + 1]);
+    const unsigned int j0 = ws.base[bot] + (c - ws.chunk_base[bot]) * ws.chunk;
+    const unsigned int j1 = min(j0 + ws.chunk, ws.base[bot + 1]);
     EsAgg1 e;
     #pragma unroll
     for (int i = 0; i < 16; i++) { e.A[i] = (i % 5 == 0) ? 1.0 : 0.0; e.C[i] = 0.0; e.J[i] = 0.0; }
@@ -468,8 +470,8 @@ es_agg2_kernel(EsWs ws)
     const unsigned int c = blockIdx.x * QS_WAVE + threadIdx.x;
     if (c >= ws.chunk_base[256]) return;
     const int bot = es_bot_of(ws.chunk_base, c);
-    const unsigned int j0 = ws.base[bot] + (c - ws.chunk_base[bot]) * ES_CHUNK;
-    const unsigned int j1 = min(j0 + ES_CHUNK, ws.base[bot + 1]);
+    const unsigned int j0 = ws.base[bot] + (c - ws.chunk_base[bot]) * ws.chunk;
+    const unsigned int j1 = min(j0 + ws.chunk, ws.base[bot + 1]);
     double s[4], A[16];
     {
         const EsStart st = ws.start[c];
@@ -758,7 +760,16 @@ es_fold_kernel(EsWs ws, QsBatch b, const double *__restrict__ recv_time, double 
 // ---- host side ------------------------------------------------------------------------------------
 static inline size_t es_align(size_t v) { return (v + 255) & ~(size_t)255; }
 
-static size_t es_max_chunks(const qs_ctx *c, size_t n) { return n / ES_CHUNK + (size_t)c->cfg.max_agent + 2; }
+static size_t es_max_chunks(const qs_ctx *c, size_t n) { return n / ES_CHUNK_MIN + (size_t)c->cfg.max_agent + 2; }
+
+static unsigned int es_chunk_for(const qs_ctx *c, size_t n)
+{
+    // ~256 chunks for a bot with an even share of the batch
+    size_t want = n / ((size_t)c->cfg.max_agent * 256);
+    unsigned int ch = ES_CHUNK_MIN;
+    while (ch < ES_CHUNK_MAX && ch < want) ch <<= 1;
+    return ch;
+}
 
 size_t qs_ekf_scan_workspace_bytes(const qs_ctx *c, size_t n)
 {
@@ -782,6 +793,7 @@ hipError_t qs_launch_ekf_scan(qs_ctx *c, size_t n, const double *d_time, hipStre
     }
     const size_t cap = c->cap_batch, ch = es_max_chunks(c, cap);
     EsWs ws;
+    ws.chunk = es_chunk_for(c, n);
     char *p = (char *)c->d_ekf_ws;
     ws.count = (unsigned int *)p; p += es_align(256 * 4);
     ws.cmax = (unsigned long long *)p; p += es_align(ch * 8);           // adjacent to count: one memset clears both
@@ -798,7 +810,7 @@ hipError_t qs_launch_ekf_scan(qs_ctx *c, size_t n, const double *d_time, hipStre
     if (e != hipSuccess) return e;
     const int ma = c->cfg.max_agent;
     const double t0 = (double)c->next_seq;
-    const unsigned int chunks = (unsigned int)es_max_chunks(c, n);
+    const unsigned int chunks = (unsigned int)(n / ws.chunk + (size_t)c->cfg.max_agent + 2);
     unsigned int cnt_blocks = (unsigned int)((n + 255) / 256);
     if (cnt_blocks > 1024) cnt_blocks = 1024;
     hipLaunchKernelGGL(es_count_kernel, dim3(cnt_blocks), dim3(256), 0, st, n, c->b, ma, ws.count);
