@@ -150,7 +150,7 @@ qs_slam_index_kernel(size_t n, QsBatch b, QsSlamBatch sb, const QsGraphDev *__re
 // ---- the chain: one workgroup (CH_WAVES waves) per pose graph ------------------------------------
 // Per window: wave 0 loads the window's events and prepares them SIMD-across-events (pose with the
 // drift at window start, eligibility, bucket key and 3x3 neighbour mask); the eligible events are
-// then queried one per wave, in parallel; wave 0 commits closures in node order and appends the
+// then queried, one wave per agent (its events in order, until the first match); wave 0 commits closures in node order and appends the
 // window's landmarks to the log and the spatial index.  A lone wave issues roughly one instruction
 // per 4-8 cycles, so everything that can be done once per window instead of once per query is.
 #define CH_WAVES 16
@@ -214,7 +214,7 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
     __shared__ unsigned int s_acnt[QS_MAX_AGENT + 1];
     __shared__ long long w_idx[32], w_kb[32], w_ridx[32];
     __shared__ double w_x[32], w_y[32], w_rx[32], w_ry[32];
-    __shared__ int w_type[32];
+    __shared__ int w_type[32], w_agent[32];
     __shared__ unsigned int w_nbm[32];
     __shared__ long long n_idx[32];            // next window's events, prefetched by the last wave
     __shared__ double n_px[32], n_py[32];
@@ -271,7 +271,7 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
             bucket_prepare(x, y, type, bg, dir_slab, kb, nbm);
             if (lane < 32) {
                 w_idx[lane] = idx; w_x[lane] = x; w_y[lane] = y; w_type[lane] = type;
-                w_kb[lane] = kb; w_nbm[lane] = nbm; w_ridx[lane] = LL_MAX;
+                w_kb[lane] = kb; w_nbm[lane] = nbm; w_ridx[lane] = LL_MAX; w_agent[lane] = a;
             }
             const unsigned long long em = __ballot(elig);
             const int kw = __popcll(__ballot(inw));
@@ -298,11 +298,16 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
         // ---- phase B (all waves): one eligible event per wave at a time.  lane = (bucket of the
         // 3x3 neighbourhood, entry of that bucket's current 7-entry node): a node scan is three
         // coalesced row loads (idx, x, y of 9 nodes) ---------------------------------------------------
+        // Only an agent's FIRST eligible event with a match closes the loop (:304-318), so the
+        // eligible events of one agent are queried in order and the rest skipped once one matched
+        // (they almost always match at once: the barrier below then waits for ~one query per agent
+        // instead of the slowest of all the window's events).  Agent a belongs to wave a % CH_WAVES.
         {
-            int qn = 0;
-            for (unsigned long long qrem = emask; qrem; qrem &= qrem - 1, qn++) {
-                if (qn % CH_WAVES != wave) continue;
+            unsigned int done = 0;                      // bit a / CH_WAVES: agent a has its match
+            for (unsigned long long qrem = emask; qrem; qrem &= qrem - 1) {
                 const int src = __ffsll((long long)qrem) - 1;
+                const int qa = w_agent[src];
+                if ((qa & (CH_WAVES - 1)) != wave || ((done >> (qa / CH_WAVES)) & 1u)) continue;
                 const int nbk = lane / QS_NODE_CAP, se = lane % QS_NODE_CAP;
                 const int last_lane = min(nbk * QS_NODE_CAP + QS_NODE_CAP - 1, 63);
                 const double qx = w_x[src], qy = w_y[src];
@@ -372,7 +377,10 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
                     }
                     if (__ballot(beyond)) break;
                 }
-                if (lane == 0 && gbest != LL_MAX) { w_ridx[src] = gbest; w_rx[src] = wx; w_ry[src] = wy; }
+                if (gbest != LL_MAX) {
+                    done |= 1u << (qa / CH_WAVES);
+                    if (lane == 0) { w_ridx[src] = gbest; w_rx[src] = wx; w_ry[src] = wy; }
+                }
             }
         }
         if (fetcher) { n_idx[lane] = f_idx; n_a[lane] = f_a; n_type[lane] = f_type; n_px[lane] = f_px; n_py[lane] = f_py; }

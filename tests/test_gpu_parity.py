@@ -593,7 +593,8 @@ def test_api_edge_cases_and_errors(pkg):
         assert m.last_batch()[0].tolist() == [0]                # non-finite pose: dropped (CPython would raise)
     # landmark types above 5 and poses outside the bucket grid still close loops (side list)
     P = pkg.protocol
-    pk = [P.pack_packet(1, 50.0 + 0.01 * (i % 3), 0.0, 0.0, i, 0, 0.0, 0.0, 0.0, 0.0, 9 if i % 10 == 0 else 0) for i in range(200)]
+    # (long enough that the side list in HBM is consulted, not only the LDS ring of recent landmarks)
+    pk = [P.pack_packet(1, 50.0 + 0.01 * (i % 3), 0.0, 0.0, i, 0, 0.0, 0.0, 0.0, 0.0, 9 if i % 10 == 0 else 0) for i in range(6000)]
     with pkg.QuasarMapper() as m:                               # 200x200 grid at (-5,-5): x = 50 is far outside
         m.ingest(pk)
         o = orc.OracleMapper()

@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""SLAM chain: stage time and cycles per window (prepare / query / commit) on the C2 stream."""
+import importlib, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+PKG = "distributed-multi-agent-slam-swarm-robotics-system_amd"
+import torch
+pkg = importlib.import_module(PKG)
+replay = importlib.import_module(PKG + ".replay")
+B = int(sys.argv[1]) if len(sys.argv) > 1 else (1 << 18)
+session, _ = replay.telemetry_csv_to_packets()
+d = torch.from_numpy(replay.cycle_stream(session, B)).cuda()
+m = pkg.QuasarMapper(4096, 0.05, -102.4, -102.4, max_agent=2, raycast_mode=1 if len(sys.argv) > 2 else 0)
+m.set_stream(torch.cuda.current_stream().cuda_stream)
+m.reset(); m.ingest_device(d.data_ptr(), B, 42, 0, 0, seq0=0); m.sync()
+m.reset(); m.timing_enable(True); m.ingest_device(d.data_ptr(), B, 42, 0, 0, seq0=0); m.sync()
+c = m.counters(); st = m.stage_times()
+w = c["slam_windows"]
+print(json.dumps({"windows": w, "slam_ms": st["slam"][0] / max(st["slam"][1], 1), "cyc_per_window": c["slam_cycles"] / w,
+                  "A": c["slam_cyc_prepare"] / w, "B": c["slam_cyc_query"] / w, "C": c["slam_cyc_commit"] / w,
+                  "rounds": c["slam_rounds"] / w, "node_iters": c["slam_node_iters"] / w}))
