@@ -89,6 +89,25 @@ def pmc_traffic_bytes(batch, counts):
     return total
 
 
+def measured_copy_gbs(torch, dev):
+    """Device-to-device copy bandwidth of this GPU in this run (bytes read + bytes written per second):
+    the practical HBM ceiling next to the 8 TB/s spec peak."""
+    n = 1 << 30
+    a = torch.empty(n, dtype=torch.uint8, device=dev)
+    b = torch.empty_like(a)
+    a.zero_(); b.copy_(a)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 10
+    ev0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    ev1.record()
+    torch.cuda.synchronize()
+    ms = ev0.elapsed_time(ev1) / reps
+    del a, b
+    return 2.0 * n / (ms * 1e-3) / 1e9
+
+
 def main():
     args = parse()
     import torch
@@ -162,6 +181,7 @@ def main():
     ray_avg_s = (ray_ms / max(ray_n, 1)) * 1e-3
     achieved = alg_bytes / ray_avg_s / 1e9 if ray_avg_s > 0 else 0.0
 
+    copy_gbs = measured_copy_gbs(torch, dev) if rank == 0 else 0.0
     if rank == 0:
         out = {
             "metric": "QuasarPackets/sec into 4096^2 grid",
@@ -186,7 +206,8 @@ def main():
                          "traffic": pmc_traffic_bytes(B, not args.no_counts),
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "algorithmic_bytes_rule": "42 B/packet + in-bounds cell writes x (8 B stamp RMW + 8 B counter RMW)",
-                         "avg_launch_ms": ray_avg_s * 1e3},
+                         "avg_launch_ms": ray_avg_s * 1e3,
+                         "copy_peak_measured": copy_gbs, "frac_of_copy_peak": achieved / copy_gbs if copy_gbs > 0 else None},
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(stream, G, args.cpu_sample, bool(args.ekf), np.arange(B) * 0.25,
