@@ -27,6 +27,7 @@
 // each ray covers; the per-cell work happens in LDS.
 #include "qs_internal.h"
 #include "raycast_common.h"
+#include <cstdlib>
 
 #define QT_TILE 64                       // tile edge in cells: 64 x 64 x u32 = 16 KiB of LDS
 #define QT_TILE_SHIFT 6
@@ -536,7 +537,10 @@ hipError_t qs_launch_raycast_tiled(qs_ctx *c, size_t n, uint64_t seq0)
     hipLaunchKernelGGL(qs_tile_scan_kernel, dim3(1), dim3(1024), 0, c->stream, ws);
     hipLaunchKernelGGL(qs_scatter_kernel, dim3(ws.nwg), dim3(QT_BIN_BLOCK), lds, c->stream, n, c->b, ws,
                        c->cfg.size, ord_base, ord_stride);
-    const unsigned int raster_wgs = (unsigned int)(max_items < QT_RASTER_WGS ? max_items : QT_RASTER_WGS);
+    // QS_RASTER_WGS (environment, read once): fewer persistent raster workgroups than the default -- a tuning
+    // knob, and how the tests reach the long-run paths (tile changes inside a run, the 31-item flush)
+    static const int env_wgs = [] { const char *e = getenv("QS_RASTER_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : QT_RASTER_WGS; }();
+    const unsigned int raster_wgs = (unsigned int)(max_items < (size_t)env_wgs ? max_items : (size_t)env_wgs);
     if (c->cfg.enable_counts)
         hipLaunchKernelGGL(qs_raster_kernel<true>, dim3(raster_wgs), dim3(QT_BLOCK), 0, c->stream, ws,
                            c->cfg.size, c->d_stamps, c->d_counts, c->d_counters);

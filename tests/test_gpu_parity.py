@@ -11,7 +11,7 @@ import struct
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, load_pkg
+from conftest import GOLDEN, ROOT, load_pkg
 from oracle import oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -738,3 +738,33 @@ def test_odd_geometries_adversarial(pkg, size, res, span, mode):
         assert m.counters()["cells"] == o.n_cells_written
         assert (m.closures(0)[0] == o.closures(0)[0]).all()
         assert (m.frontier_cells() == orc.frontier_cells(o.grid)).all()
+
+
+def test_raster_long_runs_flush_and_tile_changes(pkg):
+    """The persistent raster workgroups accumulate consecutive work items of a tile in LDS (16-bit counters:
+    forced merge every 31 items) and merge when the tile changes.  With the default 1024 workgroups a run is
+    3 items at 1 M packets, so the long-run paths are reached here by asking for 4 workgroups
+    (QS_RASTER_WGS is read when the first batch is rastered: own process)."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import importlib, os, sys, hashlib, numpy as np
+        sys.path.insert(0, %r)
+        pkg = importlib.import_module(%r)
+        replay = importlib.import_module(%r + ".replay")
+        session, _ = replay.telemetry_csv_to_packets()
+        n = 300_000
+        for stream, bots, bpg in ((replay.cycle_stream(session, n), 2, 0), (replay.multi_bot_stream(session, 16, n), 16, 2)):
+            out = []
+            for mode in (1, 2):              # direct (one global atomic per cell) vs tiled
+                with pkg.QuasarMapper(4096, 0.05, -102.4, -102.4, max_agent=bots, bots_per_graph=bpg, raycast_mode=mode) as m:
+                    m.ingest_array(stream)
+                    h, mi = m.counts()
+                    out.append((hashlib.sha256(m.grid_i8().tobytes()).hexdigest(), int(h.sum()), int(mi.sum()),
+                                hashlib.sha256(h.tobytes()).hexdigest(), hashlib.sha256(mi.tobytes()).hexdigest(), m.counters()["cells"]))
+            assert out[0] == out[1], (bots, out)
+            assert out[0][1] + out[0][2] == out[0][5]
+        print("OK")
+    """) % (ROOT, pkg.__name__, pkg.__name__)
+    env = dict(os.environ, QS_RASTER_WGS="4")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
