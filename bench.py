@@ -65,7 +65,7 @@ def cpu_baseline(stream, grid, sample, ekf, times, bots=2, bpg=0):
                       f"host has {os.cpu_count()} logical CPUs"}
 
 
-RAYCAST_KERNELS = ("qs_rays_kernel", "qs_table_scan_kernel", "qs_tile_scan_kernel", "qs_scatter_kernel",
+RAYCAST_KERNELS = ("qs_rays_kernel", "qs_table_scan_kernel", "qs_scatter_kernel",
                    "qs_raster_kernel")
 
 
@@ -200,7 +200,7 @@ def main():
                        "sharding": f"by agent, {world} x {args.bots} bots"},
             "stages_ms_per_step": {k: (v[0] / max(v[1], 1)) for k, v in stages.items() if v[1]},
             "counters_per_step": cnt,
-            "roofline": {"bound": "hbm", "kernel": "K1 raycast stage (qs_rays + 2 scans + qs_scatter + qs_raster)",
+            "roofline": {"bound": "hbm", "kernel": "K1 raycast stage (qs_rays + qs_table_scan + qs_scatter + qs_raster)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic_bytes(B, not args.no_counts),

@@ -16,7 +16,7 @@
 //                                of the table T[wg][tile].  Rays longer than one tile (fine
 //                                resolutions) are written to the grid directly.
 //   pass B1 qs_table_scan_kernel per tile: exclusive scan of its column of T over the workgroups.
-//   pass B2 qs_tile_scan_kernel  exclusive scans over the tiles: record base and work-item base.
+//   pass B2 (inside pass C)      exclusive scans over the tiles: record base and work-item base.
 //   pass C  qs_scatter_kernel    same workgroup decomposition as A: LDS cursors (= table row +
 //                                tile base) hand out record slots; one 16-byte record per
 //                                overlapped tile (<= 2x2 per ray).
@@ -217,43 +217,42 @@ qs_table_scan_kernel(QtWorkspace ws)
     if (live && seg == 0) ws.tile_count[t] = total;
 }
 
-// ---- pass B2: one workgroup, two exclusive scans over the tiles --------------------------------
-__global__ void __launch_bounds__(1024)
-qs_tile_scan_kernel(QtWorkspace ws)
-{
-    __shared__ unsigned int s_rec[1024], s_chk[1024];
-    const int tid = threadIdx.x;
-    const int per = (ws.n_tiles + 1023) / 1024;
-    const int lo = min(tid * per, ws.n_tiles), hi = min(lo + per, ws.n_tiles);
-    unsigned int a = 0, c = 0;
-    for (int t = lo; t < hi; t++) { const unsigned int v = ws.tile_count[t]; a += v; c += (v + QT_CHUNK - 1) / QT_CHUNK; }
-    s_rec[tid] = a; s_chk[tid] = c;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {        // Hillis-Steele inclusive scan of the partials
-        unsigned int va = 0, vc = 0;
-        if (tid >= off) { va = s_rec[tid - off]; vc = s_chk[tid - off]; }
-        __syncthreads();
-        s_rec[tid] += va; s_chk[tid] += vc;
-        __syncthreads();
-    }
-    unsigned int ra = s_rec[tid] - a, rc = s_chk[tid] - c;
-    for (int t = lo; t < hi; t++) {
-        const unsigned int v = ws.tile_count[t];
-        ws.tile_base[t] = ra; ws.chunk_base[t] = rc;
-        ra += v; rc += (v + QT_CHUNK - 1) / QT_CHUNK;
-    }
-    if (tid == 1023) { ws.tile_base[ws.n_tiles] = s_rec[1023]; ws.chunk_base[ws.n_tiles] = s_chk[1023]; }
-}
-
 // ---- pass C: scatter tile records ---------------------------------------------------------------
 __global__ void __launch_bounds__(QT_BIN_BLOCK)
 qs_scatter_kernel(size_t n, QsBatch b, QtWorkspace ws, int size, unsigned long long ord_base,
                   unsigned long long ord_stride)
 {
     extern __shared__ unsigned int s_cur[];                        // [n_tiles] next record slot per tile
-    const int tid = threadIdx.x;
+    __shared__ unsigned int s_wrec[QT_BIN_BLOCK / QS_WAVE], s_wchk[QT_BIN_BLOCK / QS_WAVE];
+    const int tid = threadIdx.x, lane = tid & (QS_WAVE - 1), wave = tid >> 6;
     const unsigned int *row = ws.table + (size_t)blockIdx.x * ws.n_tiles;
-    for (int t = tid; t < ws.n_tiles; t += QT_BIN_BLOCK) s_cur[t] = ws.tile_base[t] + row[t];
+    // pass B2, folded in: every workgroup scans the tile counts itself (16 KB of L2-resident reads, two
+    // barriers) instead of waiting for a one-workgroup kernel in between: record base of every tile into
+    // the LDS cursors; workgroup 0 also publishes record base and work-item base for the raster pass
+    {
+        const int per = (ws.n_tiles + QT_BIN_BLOCK - 1) / QT_BIN_BLOCK;
+        const int lo = min(tid * per, ws.n_tiles), hi = min(lo + per, ws.n_tiles);
+        unsigned int a = 0, c = 0;
+        for (int t = lo; t < hi; t++) { const unsigned int v = ws.tile_count[t]; a += v; c += (v + QT_CHUNK - 1) / QT_CHUNK; }
+        unsigned int ia = a, ic = c;                               // inclusive scan inside the wave
+        #pragma unroll
+        for (int off = 1; off < QS_WAVE; off <<= 1) {
+            const unsigned int va = __shfl_up(ia, off), vc = __shfl_up(ic, off);
+            if (lane >= off) { ia += va; ic += vc; }
+        }
+        if (lane == QS_WAVE - 1) { s_wrec[wave] = ia; s_wchk[wave] = ic; }
+        __syncthreads();
+        unsigned int ra = ia - a, rc = ic - c;
+        for (int w = 0; w < wave; w++) { ra += s_wrec[w]; rc += s_wchk[w]; }
+        const bool pub = blockIdx.x == 0;
+        for (int t = lo; t < hi; t++) {
+            const unsigned int v = ws.tile_count[t];
+            s_cur[t] = ra + row[t];
+            if (pub) { ws.tile_base[t] = ra; ws.chunk_base[t] = rc; }
+            ra += v; rc += (v + QT_CHUNK - 1) / QT_CHUNK;
+        }
+        if (pub && tid == QT_BIN_BLOCK - 1) { ws.tile_base[ws.n_tiles] = ra; ws.chunk_base[ws.n_tiles] = rc; }
+    }
     __syncthreads();
     const size_t r0 = 4 * (size_t)blockIdx.x * ws.pk_per_wg;
     const size_t r1 = (r0 + 4 * ws.pk_per_wg < 4 * n) ? r0 + 4 * ws.pk_per_wg : 4 * n;
@@ -534,7 +533,6 @@ hipError_t qs_launch_raycast_tiled(qs_ctx *c, size_t n, uint64_t seq0)
     }
     hipLaunchKernelGGL(qs_table_scan_kernel, dim3((ws.n_tiles + QT_SCAN_TILES - 1) / QT_SCAN_TILES),
                        dim3(QT_SCAN_TILES * QT_SCAN_SEGS), 0, c->stream, ws);
-    hipLaunchKernelGGL(qs_tile_scan_kernel, dim3(1), dim3(1024), 0, c->stream, ws);
     hipLaunchKernelGGL(qs_scatter_kernel, dim3(ws.nwg), dim3(QT_BIN_BLOCK), lds, c->stream, n, c->b, ws,
                        c->cfg.size, ord_base, ord_stride);
     // QS_RASTER_WGS (environment, read once): fewer persistent raster workgroups than the default -- a tuning
