@@ -155,6 +155,7 @@ qs_slam_index_kernel(size_t n, QsBatch b, QsSlamBatch sb, const QsGraphDev *__re
 // per 4-8 cycles, so everything that can be done once per window instead of once per query is.
 #define CH_WAVES 16
 #define CH_THREADS (CH_WAVES * QS_WAVE)
+#define CH_INS (CH_WAVES - 2)       // the wave that moves a committed window into the HBM index
 
 // barrier that orders LDS traffic only (the two intra-window hand-offs go through LDS; a full
 // __syncthreads would also wait for every outstanding global store to be acknowledged)
@@ -196,6 +197,70 @@ __device__ inline void bucket_prepare(double x, double y, int type, const QsBuck
     nbmask = (cy >= 1 ? xm : 0u) | ((cy >= 0 && cy < bg.nby) ? xm << 3 : 0u) | (cy + 1 < bg.nby ? xm << 6 : 0u);
 }
 
+
+// Landmark log and bucket index of the window committed last (LDS arrays i_*): run by wave CH_INS while
+// the next window's queries are in flight.  Those queries read the index for everything older and the
+// LDS arrays for this window, so nothing waits for these stores; they are complete (vmcnt) before the
+// barrier that ends the query phase, i.e. before the window after next looks for them in HBM.
+__device__ inline void chain_insert_window(const QsGraphDev &G, const long long *i_idx, const long long *i_kb, const double *i_x,
+                                           const double *i_y, const int *i_type, int k, int lane, long long &n_lms,
+                                           long long &n_misc, unsigned int &pool)
+{
+    const bool inw = lane < k;
+    const long long idx = lane < 32 ? i_idx[lane] : LL_MAX;
+    const long long kb = lane < 32 ? i_kb[lane] : -1;
+    const double x = lane < 32 ? i_x[lane] : 0, y = lane < 32 ? i_y[lane] : 0;
+    const int type = lane < 32 ? i_type[lane] : 0;
+    // self.landmarks.append((x, y, landmark_type, idx))  :288
+    const long long log_slot = n_lms + lane;
+    if (inw && log_slot < G.cap_lms) {
+        G.lm_x[log_slot] = x; G.lm_y[log_slot] = y; G.lm_idx[log_slot] = idx; G.lm_type[log_slot] = (unsigned char)type;
+    }
+    // spatial index insert: events of one bucket are appended in lane (= node) order
+    const bool inb = inw && kb >= 0;                              // the centre bucket exists
+    const long long key = inb ? kb : -1;
+    const bool is_misc = inw && !inb;
+    {
+        const unsigned long long mm = __ballot(is_misc);
+        if (is_misc && log_slot < G.cap_lms) G.misc[n_misc + __popcll(mm & ((1ull << lane) - 1))] = (unsigned int)log_slot;
+        n_misc += __popcll(mm);
+    }
+    QsDirEntry de = {0, 0, 0, 0};
+    if (inb) de = G.dir[kb];
+    for (unsigned long long rem = __ballot(inb); rem;) {
+        const int ld = __ffsll((long long)rem) - 1;
+        const long long kk = rl64(key, ld);
+        const unsigned long long grp = __ballot(inb && key == kk);
+        const int gsize = __popcll(grp);
+        const unsigned int head = __builtin_amdgcn_readlane(de.head, ld), tail = __builtin_amdgcn_readlane(de.tail, ld);
+        const unsigned int tc = head ? __builtin_amdgcn_readlane(de.tail_cnt, ld) : QS_NODE_CAP;   // no tail node yet: "full"
+        const unsigned int total = tc + gsize;
+        const unsigned int nn = total > QS_NODE_CAP ? (total - QS_NODE_CAP + QS_NODE_CAP - 1) / QS_NODE_CAP : 0;
+        const unsigned int base = pool;
+        if (inb && key == kk && (long long)base + nn <= G.cap_lms) {
+            const unsigned int p = tc + __popcll(grp & ((1ull << lane) - 1));
+            const unsigned int nd = p < QS_NODE_CAP ? tail : base + (p - QS_NODE_CAP) / QS_NODE_CAP;
+            const unsigned int sl = p < QS_NODE_CAP ? p : (p - QS_NODE_CAP) % QS_NODE_CAP;
+            QsLmNode *np = G.nodes + nd;
+            np->idx[sl] = idx; np->x[sl] = x; np->y[sl] = y;
+            if (lane == ld) {
+                QsDirEntry upd;
+                upd.head = head; upd.tail = tail; upd.tail_cnt = total; upd.pad = 0;
+                if (nn) {
+                    for (unsigned int q = 0; q + 1 < nn; q++) G.nd_next[base + q] = base + q + 1;
+                    if (head) G.nd_next[tail] = base; else upd.head = base;
+                    upd.tail = base + nn - 1;
+                    upd.tail_cnt = total - QS_NODE_CAP * nn;
+                }
+                G.dir[kk] = upd;
+            }
+        }
+        pool += nn;
+        rem &= ~grp;
+    }
+    n_lms += k;
+}
+
 __global__ void __launch_bounds__(CH_THREADS)
 qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGeom bg, int bots_per_graph,
                      int max_agent, int win, int min_between, double r2thr, double corr,
@@ -219,6 +284,10 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
     __shared__ long long n_idx[32];            // next window's events, prefetched by the last wave
     __shared__ double n_px[32], n_py[32];
     __shared__ int n_a[32], n_type[32];
+    __shared__ long long i_idx[32], i_kb[32];   // the window just committed: its landmarks, final poses (inserted
+    __shared__ double i_x[32], i_y[32];         // into the index by wave CH_INS during the next window's queries)
+    __shared__ int i_type[32];
+    __shared__ int s_ik;
     __shared__ int s_k;
     __shared__ unsigned long long s_emask;
     __shared__ long long s_nmisc;
@@ -229,11 +298,13 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
         s_last[t] = last_closure[bot0 + t];
         s_acnt[t] = 0;
     }
-    if (tid == 0) s_nmisc = G.n_misc;
+    if (tid == 0) { s_nmisc = G.n_misc; s_ik = 0; }
+    if (tid < 32) { i_idx[tid] = LL_MAX; i_kb[tid] = -1; i_x[tid] = 0; i_y[tid] = 0; i_type[tid] = 0; }
     __syncthreads();
 
     const unsigned int e0 = sb.ev_base[g], e1 = sb.ev_base[g + 1];
-    long long n_lms = G.n_lms, n_cls = G.n_cls, n_misc = G.n_misc;     // authoritative in wave 0
+    long long n_cls = G.n_cls;                                         // authoritative in wave 0
+    long long n_lms = G.n_lms, n_misc = G.n_misc;                      // authoritative in wave CH_INS
     unsigned int pool = G.nodes_used;
     const long long dir_slab = (long long)bg.nbx * bg.nby;
     unsigned long long st_windows = 0, st_rounds = 0, st_iters = 0, st_misc = 0, st_a = 0, st_b = 0, st_c = 0;
@@ -253,7 +324,6 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
         n_px[lane] = have ? sb.ev_px[e0 + lane] : 0; n_py[lane] = have ? sb.ev_py[e0 + lane] : 0;
     }
     __syncthreads();
-    QsDirEntry de = {0, 0, 0, 0};
 
     for (unsigned int e = e0; e < e1;) {
         // ---- phase A (wave 0): the next events whose node index is < first + win ---------------------
@@ -289,10 +359,11 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
             const unsigned int q = e + k + lane;
             f_idx = sb.ev_node[q]; f_a = sb.ev_agent[q]; f_type = sb.ev_type[q]; f_px = sb.ev_px[q]; f_py = sb.ev_py[q];
         }
-        // wave 0 fetches the directory entries its inserts will need (re-posed lanes reload later)
-        if (wave == 0) {
-            de = QsDirEntry{0, 0, 0, 0};
-            if (inw && kb >= 0 && ((nbm >> 4) & 1u)) de = G.dir[kb];
+        // wave CH_INS moves the window committed last into the index while the queries run
+        if (wave == CH_INS && s_ik > 0) {
+            chain_insert_window(G, i_idx, i_kb, i_x, i_y, i_type, s_ik, lane, n_lms, n_misc, pool);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the stores are done before the phase ends ...
+            if (lane == 0) s_nmisc = n_misc;                         // ... and before the side list's new length shows
         }
 
         // ---- phase B (all waves): one eligible event per wave at a time.  lane = (bucket of the
@@ -377,6 +448,25 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
                     }
                     if (__ballot(beyond)) break;
                 }
+                // the window committed last is not in the index yet: its landmarks are in LDS, in node order
+                {
+                    bool cand = false;
+                    long long li = LL_MAX; double lx = 0, ly = 0;
+                    if (lane < 32) {
+                        li = i_idx[lane];
+                        if (li <= limit && i_type[lane] == qtype) {
+                            lx = i_x[lane]; ly = i_y[lane];
+                            const double dx = qx - lx, dy = qy - ly;
+                            cand = dx * dx + dy * dy < r2thr;
+                        }
+                    }
+                    const unsigned long long cm = __ballot(cand);
+                    if (cm) {
+                        const int w = __ffsll((long long)cm) - 1;
+                        const long long widx = rl64(li, w);
+                        if (widx < gbest) { gbest = widx; wx = __shfl(lx, w); wy = __shfl(ly, w); }
+                    }
+                }
                 if (gbest != LL_MAX) {
                     done |= 1u << (qa / CH_WAVES);
                     if (lane == 0) { w_ridx[src] = gbest; w_rx[src] = wx; w_ry[src] = wy; }
@@ -425,64 +515,23 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
                     x = px + s_drift[a][0];
                     y = py + s_drift[a][1];
                     bucket_prepare(x, y, type, bg, dir_slab, kb, nbm);
-                    de = QsDirEntry{0, 0, 0, 0};
-                    if (kb >= 0 && ((nbm >> 4) & 1u)) de = G.dir[kb];
                 }
             }
-            // self.landmarks.append((x, y, landmark_type, idx))  :288
-            const long long log_slot = n_lms + lane;
-            if (inw && log_slot < G.cap_lms) {
-                G.lm_x[log_slot] = x; G.lm_y[log_slot] = y; G.lm_idx[log_slot] = idx; G.lm_type[log_slot] = (unsigned char)type;
+            // hand the window's landmarks (final poses) to wave CH_INS: self.landmarks.append(...)  :288
+            if (lane < 32) {
+                i_idx[lane] = inw ? idx : LL_MAX; i_x[lane] = x; i_y[lane] = y; i_type[lane] = inw ? type : 0;
+                i_kb[lane] = (inw && kb >= 0 && ((nbm >> 4) & 1u)) ? kb : -1;      // -1: not in the directory (side list)
             }
-            // spatial index insert: events of one bucket are appended in lane (= node) order
-            const bool inb = inw && kb >= 0 && ((nbm >> 4) & 1u);      // the centre bucket exists
-            const long long key = inb ? kb : -1;
-            const bool is_misc = inw && !inb;
-            {
-                const unsigned long long mm = __ballot(is_misc);
-                if (is_misc && log_slot < G.cap_lms) G.misc[n_misc + __popcll(mm & ((1ull << lane) - 1))] = (unsigned int)log_slot;
-                n_misc += __popcll(mm);
-            }
-            for (unsigned long long rem = __ballot(inb); rem;) {
-                const int ld = __ffsll((long long)rem) - 1;
-                const long long kk = rl64(key, ld);
-                const unsigned long long grp = __ballot(inb && key == kk);
-                const int gsize = __popcll(grp);
-                const unsigned int head = __builtin_amdgcn_readlane(de.head, ld), tail = __builtin_amdgcn_readlane(de.tail, ld);
-                const unsigned int tc = head ? __builtin_amdgcn_readlane(de.tail_cnt, ld) : QS_NODE_CAP;   // no tail node yet: "full"
-                const unsigned int total = tc + gsize;
-                const unsigned int nn = total > QS_NODE_CAP ? (total - QS_NODE_CAP + QS_NODE_CAP - 1) / QS_NODE_CAP : 0;
-                const unsigned int base = pool;
-                if (inb && key == kk && (long long)base + nn <= G.cap_lms) {
-                    const unsigned int p = tc + __popcll(grp & ((1ull << lane) - 1));
-                    const unsigned int nd = p < QS_NODE_CAP ? tail : base + (p - QS_NODE_CAP) / QS_NODE_CAP;
-                    const unsigned int sl = p < QS_NODE_CAP ? p : (p - QS_NODE_CAP) % QS_NODE_CAP;
-                    QsLmNode *np = G.nodes + nd;
-                    np->idx[sl] = idx; np->x[sl] = x; np->y[sl] = y;
-                    if (lane == ld) {
-                        QsDirEntry upd;
-                        upd.head = head; upd.tail = tail; upd.tail_cnt = total; upd.pad = 0;
-                        if (nn) {
-                            for (unsigned int q = 0; q + 1 < nn; q++) G.nd_next[base + q] = base + q + 1;
-                            if (head) G.nd_next[tail] = base; else upd.head = base;
-                            upd.tail = base + nn - 1;
-                            upd.tail_cnt = total - QS_NODE_CAP * nn;
-                        }
-                        G.dir[kk] = upd;
-                    }
-                }
-                pool += nn;
-                rem &= ~grp;
-            }
-            n_lms += k;
-            if (lane == 0) s_nmisc = n_misc;
+            if (lane == 0) s_ik = k;
         }
         e += k;
-        // this window's stores (landmarks, directory) are ordered before the next window's loads
+        // (wave 0's closure records are only read after the kernel; the index stores of wave CH_INS were
+        // completed inside the query phase)
         __syncthreads();
         st_a += tb0 - ta0; st_b += tc0 - tb0; st_c += __builtin_amdgcn_s_memtime() - tc0;
     }
 
+    if (wave == CH_INS && s_ik > 0) chain_insert_window(G, i_idx, i_kb, i_x, i_y, i_type, s_ik, lane, n_lms, n_misc, pool);
     for (int t = tid; t < nb; t += CH_THREADS) {
         drift[2 * (bot0 + t)] = s_drift[t][0];
         drift[2 * (bot0 + t) + 1] = s_drift[t][1];
@@ -497,14 +546,16 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
     }
     if (tid == 0) {
         atomicAdd(&counters[QS_CNT_CLOSURES], (unsigned long long)(n_cls - G.n_cls));
-        atomicAdd(&counters[QS_CNT_LANDMARKS], (unsigned long long)(n_lms - G.n_lms));
         atomicAdd(&counters[QS_CNT_SLAM_WINDOWS], st_windows);
         atomicAdd(&counters[QS_CNT_SLAM_CYC_A], st_a); atomicAdd(&counters[QS_CNT_SLAM_CYC_B], st_b); atomicAdd(&counters[QS_CNT_SLAM_CYC_C], st_c);
         atomicAdd(&counters[QS_CNT_SLAM_CYCLES], __builtin_amdgcn_s_memtime() - t0_cyc);
         atomicAdd(&counters[QS_CNT_SLAM_REALTIME], __builtin_amdgcn_s_memrealtime() - t0_real);
         graphs[g].n_nodes = G.n_nodes + sb.acc_total[g];
-        graphs[g].n_lms = n_lms;
         graphs[g].n_cls = n_cls;
+    }
+    if (wave == CH_INS && lane == 0) {
+        atomicAdd(&counters[QS_CNT_LANDMARKS], (unsigned long long)(n_lms - G.n_lms));
+        graphs[g].n_lms = n_lms;
         graphs[g].n_misc = n_misc;
         graphs[g].nodes_used = pool;
     }
