@@ -289,7 +289,7 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
     __shared__ int i_type[32];
     __shared__ int s_ik;
     __shared__ int s_k;
-    __shared__ unsigned long long s_emask;
+    __shared__ unsigned long long s_wmask[CH_WAVES];   // eligible events of the window, by the wave that owns their agent
     __shared__ long long s_nmisc;
 
     for (int t = tid; t < nb; t += CH_THREADS) {
@@ -343,15 +343,18 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
                 w_idx[lane] = idx; w_x[lane] = x; w_y[lane] = y; w_type[lane] = type;
                 w_kb[lane] = kb; w_nbm[lane] = nbm; w_ridx[lane] = LL_MAX; w_agent[lane] = a;
             }
-            const unsigned long long em = __ballot(elig);
+            // eligible events by owning wave (agent a belongs to wave a % CH_WAVES): a query wave then
+            // touches only its own events instead of walking all of the window's
+            if (lane < CH_WAVES) s_wmask[lane] = 0;
+            if (elig) atomicOr(&s_wmask[a & (CH_WAVES - 1)], 1ull << lane);
             const int kw = __popcll(__ballot(inw));
-            if (lane == 0) { s_k = kw; s_emask = em; }
+            if (lane == 0) s_k = kw;
             st_windows++;
         }
         lds_barrier();
         const unsigned long long tb0 = __builtin_amdgcn_s_memtime();
         const int k = s_k;
-        const unsigned long long emask = s_emask;
+        const unsigned long long emask = s_wmask[wave];
         // the last wave fetches the next window's events while the queries run
         long long f_idx = LL_MAX; int f_a = 0, f_type = 0; double f_px = 0, f_py = 0;
         const bool fetcher = wave == CH_WAVES - 1 && lane < 32;
@@ -378,7 +381,7 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
             for (unsigned long long qrem = emask; qrem; qrem &= qrem - 1) {
                 const int src = __ffsll((long long)qrem) - 1;
                 const int qa = w_agent[src];
-                if ((qa & (CH_WAVES - 1)) != wave || ((done >> (qa / CH_WAVES)) & 1u)) continue;
+                if ((done >> (qa / CH_WAVES)) & 1u) continue;
                 const int nbk = lane / QS_NODE_CAP, se = lane % QS_NODE_CAP;
                 const int last_lane = min(nbk * QS_NODE_CAP + QS_NODE_CAP - 1, 63);
                 const double qx = w_x[src], qy = w_y[src];
