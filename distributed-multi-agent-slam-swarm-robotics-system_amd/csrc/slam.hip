@@ -485,15 +485,9 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
             const long long m_idx = lane < 32 ? w_ridx[lane] : LL_MAX;
             const double m_x = lane < 32 ? w_rx[lane] : 0, m_y = lane < 32 ? w_ry[lane] : 0;
             const bool matched = elig && m_idx != LL_MAX;
-            // per agent, its first eligible event with a match closes the loop
-            bool closes = matched;
-            for (unsigned long long rem = __ballot(matched); rem;) {
-                const int c = __ffsll((long long)rem) - 1;
-                const int ac = __builtin_amdgcn_readlane(a, c);
-                const unsigned long long same = __ballot(matched && a == ac);
-                if (matched && a == ac && lane != c) closes = false;
-                rem &= ~same;
-            }
+            // per agent, its first eligible event with a match closes the loop: the query phase stops an
+            // agent at its first match, so a result marks exactly that event
+            const bool closes = matched;
             const unsigned long long cmask = __ballot(closes);
             if (closes) {
                 const double ex = m_x - x, ey = m_y - y;                                   // :311-312
