@@ -522,9 +522,9 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
             if (lane == 0) s_ik = k;
         }
         e += k;
-        // (wave 0's closure records are only read after the kernel; the index stores of wave CH_INS were
-        // completed inside the query phase)
-        __syncthreads();
+        // LDS hand-offs only: wave 0's closure records are read after the kernel, and the index stores of
+        // wave CH_INS were completed inside the query phase -- nothing here has to wait for HBM
+        lds_barrier();
         st_a += tb0 - ta0; st_b += tc0 - tb0; st_c += __builtin_amdgcn_s_memtime() - tc0;
     }
 
