@@ -169,10 +169,10 @@ __device__ inline void lds_barrier()
 // Bucket index along one axis.  Only consistency between insert and query matters (not the
 // reference's arithmetic): the edge exceeds the closure radius by 1e-9 relative, so two points
 // closer than the radius are never two buckets apart whatever the rounding of this product.
-__device__ inline long long bucket_coord(double v, double b0, double inv_cell)
+__device__ inline int bucket_coord(double v, double b0, double inv_cell)
 {
     const double f = floor((v - b0) * inv_cell);
-    return (fabs(f) < 1.0e9) ? (long long)f : -1000000000ll;
+    return (fabs(f) < 1.0e9) ? (int)f : -1000000000;     // one conversion instruction (f64 -> i64 is a sequence)
 }
 
 __device__ inline long long rl64(long long v, int src_lane)      // wave-uniform read of one lane
@@ -189,9 +189,9 @@ __device__ inline void bucket_prepare(double x, double y, int type, const QsBuck
 {
     kb = -1; nbmask = 0;
     if (type < 1 || type > QS_NTYPES) return;
-    const long long cx = bucket_coord(x, bg.bx0, bg.inv_cell), cy = bucket_coord(y, bg.by0, bg.inv_cell);
+    const int cx = bucket_coord(x, bg.bx0, bg.inv_cell), cy = bucket_coord(y, bg.by0, bg.inv_cell);
     if (cx < -1 || cx > bg.nbx || cy < -1 || cy > bg.nby) return;
-    kb = (type - 1) * dir_slab + cy * bg.nbx + cx;
+    kb = (type - 1) * dir_slab + (long long)(cy * bg.nbx + cx);        // |cy * nbx + cx| < 2^23: buckets per axis <= 2048
     // bit q = 3 * (dy + 1) + (dx + 1) is set when neighbour (cx + dx, cy + dy) exists
     const unsigned int xm = (cx >= 1 ? 1u : 0u) | ((cx >= 0 && cx < bg.nbx) ? 2u : 0u) | (cx + 1 < bg.nbx ? 4u : 0u);
     nbmask = (cy >= 1 ? xm : 0u) | ((cy >= 0 && cy < bg.nby) ? xm << 3 : 0u) | (cy + 1 < bg.nby ? xm << 6 : 0u);
