@@ -459,8 +459,11 @@ static int ingest_device(qs_ctx *c, const uint8_t *d_pkts, size_t n, size_t stri
     { StageTimer t(c, QS_STAGE_SLAM); HIPCHK(c, qs_launch_slam(c, n)); t.stop(); }
     {
         StageTimer t(c, QS_STAGE_RAYCAST);
-        if (c->cfg.raycast_mode == 1) HIPCHK(c, qs_launch_raycast_direct(c, n, seq0));
-        else HIPCHK(c, qs_launch_raycast_tiled(c, n, seq0));      // 0 (auto) and 2
+        // auto (0): a handful of packets (the live UDP path: <= 20 per frame) is one direct kernel instead
+        // of the four tiled passes -- same cells either way; 1 = always direct, 2 = always tiled
+        if (c->cfg.raycast_mode == 1 || (c->cfg.raycast_mode == 0 && n <= QS_DIRECT_MAX_BATCH))
+            HIPCHK(c, qs_launch_raycast_direct(c, n, seq0));
+        else HIPCHK(c, qs_launch_raycast_tiled(c, n, seq0));
         t.stop();
     }
     if (c->cfg.enable_ekf) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_ekf_done, 0));   // join

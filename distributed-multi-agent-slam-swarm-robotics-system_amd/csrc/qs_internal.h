@@ -164,6 +164,7 @@ hipError_t qs_launch_decode(qs_ctx *c, const unsigned char *d_pkts, size_t n, si
 hipError_t qs_launch_slam(qs_ctx *c, size_t n, bool raw_pose = false);
 int qs_slam_blocks(size_t n);
 // raycast.hip
+#define QS_DIRECT_MAX_BATCH 256   // raycast_mode auto: batches up to this size take the direct kernel
 hipError_t qs_launch_raycast_direct(qs_ctx *c, size_t n, uint64_t seq0);
 hipError_t qs_launch_hits(qs_ctx *c, size_t n);                 // ray end points of the resident batch (qs_last_hits)
 hipError_t qs_launch_update_rays(qs_ctx *c, const double *rx, const double *ry, const double *hx,
