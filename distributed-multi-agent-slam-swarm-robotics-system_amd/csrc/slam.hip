@@ -400,7 +400,11 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
                     long long id = LL_MAX;
                     double nx = 0, ny = 0;
                     unsigned int nxt = 0;
-                    if (node) { const QsLmNode *nd = G.nodes + node; id = nd->idx[se]; nx = nd->x[se]; ny = nd->y[se]; nxt = G.nd_next[node]; }
+                    long long lastid = LL_MAX;                         // the node's last entry: same 64-byte row as `id`,
+                    if (node) {                                         // read directly instead of a cross-lane shuffle
+                        const QsLmNode *nd = G.nodes + node;
+                        id = nd->idx[se]; lastid = nd->idx[QS_NODE_CAP - 1]; nx = nd->x[se]; ny = nd->y[se]; nxt = G.nd_next[node];
+                    }
                     const bool inlim = node != 0 && id <= limit;      // empty slots read as a huge index
                     bool newhit = false;
                     if (inlim && best == LL_MAX) {
@@ -413,7 +417,6 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
                     }
                     const unsigned long long hitm = __ballot(best != LL_MAX);
                     const unsigned long long limm = __ballot(inlim);
-                    const long long lastid = __shfl(id, last_lane);
                     // a bucket's chain goes on only if none of its entries matched, its node was full
                     // and within the limit, and its last entry is still older than the best match
                     const bool b_hit = ((hitm >> (nbk * QS_NODE_CAP)) & 0x7full) != 0;
