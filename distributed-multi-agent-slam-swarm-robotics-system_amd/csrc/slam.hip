@@ -156,6 +156,7 @@ qs_slam_index_kernel(size_t n, QsBatch b, QsSlamBatch sb, const QsGraphDev *__re
 #define CH_WAVES 16
 #define CH_THREADS (CH_WAVES * QS_WAVE)
 #define CH_INS (CH_WAVES - 2)       // the wave that moves a committed window into the HBM index
+#define CH_AGW (CH_WAVES - 3)       // query waves 1 .. CH_AGW: agent a belongs to wave 1 + a % CH_AGW
 
 // barrier that orders LDS traffic only (the two intra-window hand-offs go through LDS; a full
 // __syncthreads would also wait for every outstanding global store to be acknowledged)
@@ -277,10 +278,8 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
     __shared__ double s_drift[QS_MAX_AGENT + 1][2];
     __shared__ long long s_last[QS_MAX_AGENT + 1];
     __shared__ unsigned int s_acnt[QS_MAX_AGENT + 1];
-    __shared__ long long w_idx[32], w_kb[32], w_ridx[32];
-    __shared__ double w_x[32], w_y[32], w_rx[32], w_ry[32];
-    __shared__ int w_type[32], w_agent[32];
-    __shared__ unsigned int w_nbm[32];
+    __shared__ long long w_ridx[32];            // query results of the window: matched landmark (node index, pose)
+    __shared__ double w_rx[32], w_ry[32];
     __shared__ long long n_idx[32];            // next window's events, prefetched by the last wave
     __shared__ double n_px[32], n_py[32];
     __shared__ int n_a[32], n_type[32];
@@ -288,8 +287,6 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
     __shared__ double i_x[32], i_y[32];         // into the index by wave CH_INS during the next window's queries)
     __shared__ int i_type[32];
     __shared__ int s_ik;
-    __shared__ int s_k;
-    __shared__ unsigned long long s_wmask[CH_WAVES];   // eligible events of the window, by the wave that owns their agent
     __shared__ long long s_nmisc;
 
     for (int t = tid; t < nb; t += CH_THREADS) {
@@ -299,7 +296,7 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
         s_acnt[t] = 0;
     }
     if (tid == 0) { s_nmisc = G.n_misc; s_ik = 0; }
-    if (tid < 32) { i_idx[tid] = LL_MAX; i_kb[tid] = -1; i_x[tid] = 0; i_y[tid] = 0; i_type[tid] = 0; }
+    if (tid < 32) { i_idx[tid] = LL_MAX; i_kb[tid] = -1; i_x[tid] = 0; i_y[tid] = 0; i_type[tid] = 0; w_ridx[tid] = LL_MAX; }
     __syncthreads();
 
     const unsigned int e0 = sb.ev_base[g], e1 = sb.ev_base[g + 1];
@@ -326,35 +323,32 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
     __syncthreads();
 
     for (unsigned int e = e0; e < e1;) {
-        // ---- phase A (wave 0): the next events whose node index is < first + win ---------------------
+        // ---- phase AB: the window = the next events whose node index is < first + win.  Every wave reads
+        // it from the prefetched events; then, side by side,
+        //   wave 0         poses ALL the window's events (for the commit and the index),
+        //   waves 1..CH_AGW each agent's owner finds that agent's first eligible event, poses just that one
+        //                  itself and queries it (then the next, until a match: only an agent's FIRST eligible
+        //                  event with a match closes the loop, :304-318) -- it does not wait for wave 0,
+        //   wave CH_INS    moves the window committed last into the index,
+        //   the last wave  fetches the events after this window. -------------------------------------------
         const unsigned long long ta0 = __builtin_amdgcn_s_memtime();
+        const bool have = lane < 32 && e + lane < e1;
+        const long long v_idx = have ? n_idx[lane] : LL_MAX;
+        const int v_a = have ? n_a[lane] : 0;
+        first = rl64(v_idx, 0);
+        const bool v_inw = have && v_idx < first + win;                 // a contiguous prefix of the lanes
+        const int k = __popcll(__ballot(v_inw));
         if (wave == 0) {
-            const bool have = lane < 32 && e + lane < e1;
-            idx = LL_MAX; a = 0; type = 0; px = 0; py = 0;
-            if (have) { idx = n_idx[lane]; a = n_a[lane]; type = n_type[lane]; px = n_px[lane]; py = n_py[lane]; }
-            first = rl64(idx, 0);
-            inw = have && idx < first + win;                        // a contiguous prefix of the lanes
+            idx = v_idx; a = v_a; type = 0; px = 0; py = 0;
+            if (have) { type = n_type[lane]; px = n_px[lane]; py = n_py[lane]; }
+            inw = v_inw;
             if (!inw) { a = 0; type = 0; }
             x = raw_pose ? px : px + s_drift[a][0];                 // rx += cdx  :856
             y = raw_pose ? py : py + s_drift[a][1];                 // ry += cdy  :857
             elig = inw && (idx - s_last[a] >= min_between);         // :304
             bucket_prepare(x, y, type, bg, dir_slab, kb, nbm);
-            if (lane < 32) {
-                w_idx[lane] = idx; w_x[lane] = x; w_y[lane] = y; w_type[lane] = type;
-                w_kb[lane] = kb; w_nbm[lane] = nbm; w_ridx[lane] = LL_MAX; w_agent[lane] = a;
-            }
-            // eligible events by owning wave (agent a belongs to wave a % CH_WAVES): a query wave then
-            // touches only its own events instead of walking all of the window's
-            if (lane < CH_WAVES) s_wmask[lane] = 0;
-            if (elig) atomicOr(&s_wmask[a & (CH_WAVES - 1)], 1ull << lane);
-            const int kw = __popcll(__ballot(inw));
-            if (lane == 0) s_k = kw;
             st_windows++;
         }
-        lds_barrier();
-        const unsigned long long tb0 = __builtin_amdgcn_s_memtime();
-        const int k = s_k;
-        const unsigned long long emask = s_wmask[wave];
         // the last wave fetches the next window's events while the queries run
         long long f_idx = LL_MAX; int f_a = 0, f_type = 0; double f_px = 0, f_py = 0;
         const bool fetcher = wave == CH_WAVES - 1 && lane < 32;
@@ -368,27 +362,24 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the stores are done before the phase ends ...
             if (lane == 0) s_nmisc = n_misc;                         // ... and before the side list's new length shows
         }
-
-        // ---- phase B (all waves): one eligible event per wave at a time.  lane = (bucket of the
-        // 3x3 neighbourhood, entry of that bucket's current 7-entry node): a node scan is three
-        // coalesced row loads (idx, x, y of 9 nodes) ---------------------------------------------------
-        // Only an agent's FIRST eligible event with a match closes the loop (:304-318), so the
-        // eligible events of one agent are queried in order and the rest skipped once one matched
-        // (they almost always match at once: the barrier below then waits for ~one query per agent
-        // instead of the slowest of all the window's events).  Agent a belongs to wave a % CH_WAVES.
-        {
-            unsigned int done = 0;                      // bit a / CH_WAVES: agent a has its match
-            for (unsigned long long qrem = emask; qrem; qrem &= qrem - 1) {
+        // query waves.  lane = (bucket of the 3x3 neighbourhood, entry of that bucket's current 7-entry
+        // node): a node scan is three coalesced row loads (idx, x, y of 9 nodes)
+        if (wave >= 1 && wave <= CH_AGW) {
+            unsigned int done = 0;                      // bit a / CH_AGW: agent a has its match
+            for (unsigned long long qrem = __ballot(v_inw && (v_a % CH_AGW) + 1 == wave); qrem; qrem &= qrem - 1) {
                 const int src = __ffsll((long long)qrem) - 1;
-                const int qa = w_agent[src];
-                if ((done >> (qa / CH_WAVES)) & 1u) continue;
+                const int qa = __builtin_amdgcn_readlane(v_a, src);
+                if ((done >> (qa / CH_AGW)) & 1u) continue;
+                const long long qidx = rl64(v_idx, src);
+                if (qidx - s_last[qa] < min_between) continue;                      // :304
                 const int nbk = lane / QS_NODE_CAP, se = lane % QS_NODE_CAP;
                 const int last_lane = min(nbk * QS_NODE_CAP + QS_NODE_CAP - 1, 63);
-                const double qx = w_x[src], qy = w_y[src];
-                const int qtype = w_type[src];
-                const long long limit = w_idx[src] - min_between;                  // :300
-                const long long qkb = w_kb[src];
-                const unsigned int qnbm = w_nbm[src];
+                const double qx = raw_pose ? n_px[src] : n_px[src] + s_drift[qa][0];   // rx += cdx  :856
+                const double qy = raw_pose ? n_py[src] : n_py[src] + s_drift[qa][1];   // ry += cdy  :857
+                const int qtype = n_type[src];
+                const long long limit = qidx - min_between;                        // :300
+                long long qkb; unsigned int qnbm;
+                bucket_prepare(qx, qy, qtype, bg, dir_slab, qkb, qnbm);
                 unsigned int node = 0;
                 if (lane < 9 * QS_NODE_CAP && ((qnbm >> nbk) & 1u))
                     node = G.dir[qkb + ((nbk / 3) - 1) * (long long)bg.nbx + (nbk % 3) - 1].head;
@@ -474,14 +465,15 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
                     }
                 }
                 if (gbest != LL_MAX) {
-                    done |= 1u << (qa / CH_WAVES);
+                    done |= 1u << (qa / CH_AGW);
                     if (lane == 0) { w_ridx[src] = gbest; w_rx[src] = wx; w_ry[src] = wy; }
                 }
             }
         }
-        if (fetcher) { n_idx[lane] = f_idx; n_a[lane] = f_a; n_type[lane] = f_type; n_px[lane] = f_px; n_py[lane] = f_py; }
         lds_barrier();
         const unsigned long long tc0 = __builtin_amdgcn_s_memtime();
+        // (everyone has read this window's events: now the next ones may replace them)
+        if (fetcher) { n_idx[lane] = f_idx; n_a[lane] = f_a; n_type[lane] = f_type; n_px[lane] = f_px; n_py[lane] = f_py; }
 
         // ---- phase C (wave 0): commit, in node order ------------------------------------------------------
         if (wave == 0) {
@@ -523,12 +515,13 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
                 i_kb[lane] = (inw && kb >= 0 && ((nbm >> 4) & 1u)) ? kb : -1;      // -1: not in the directory (side list)
             }
             if (lane == 0) s_ik = k;
+            if (lane < 32) w_ridx[lane] = LL_MAX;                    // no result yet for the next window
         }
         e += k;
         // LDS hand-offs only: wave 0's closure records are read after the kernel, and the index stores of
         // wave CH_INS were completed inside the query phase -- nothing here has to wait for HBM
         lds_barrier();
-        st_a += tb0 - ta0; st_b += tc0 - tb0; st_c += __builtin_amdgcn_s_memtime() - tc0;
+        st_b += tc0 - ta0; st_c += __builtin_amdgcn_s_memtime() - tc0;
     }
 
     if (wave == CH_INS && s_ik > 0) chain_insert_window(G, i_idx, i_kb, i_x, i_y, i_type, s_ik, lane, n_lms, n_misc, pool);
