@@ -262,6 +262,34 @@ __device__ inline void chain_insert_window(const QsGraphDev &G, const long long 
     n_lms += k;
 }
 
+// The graph's pointers come out of a struct in memory, so the compiler has to treat them as FLAT
+// (could be LDS): a flat load counts on the LDS counter too, and every wait for an LDS read would
+// also wait for the node rows in flight.  The query waves read the index through global pointers.
+#define QS_GLOBAL __attribute__((address_space(1)))
+typedef const QS_GLOBAL QsLmNode *QsNodeG;
+typedef const QS_GLOBAL QsDirEntry *QsDirG;
+typedef const QS_GLOBAL unsigned int *QsU32G;
+
+// wave-uniform read of one lane of a double
+__device__ inline double rlf64(double v, int src_lane) { return __longlong_as_double(rl64(__double_as_longlong(v), src_lane)); }
+
+// wait until the commits counter (LDS) reaches `want`.  The writer (wave 0) sets it unconditionally, in
+// program order, before it reaches the phase's barrier, and no waiter holds anything wave 0 needs: the
+// wait cannot cycle.  The bound only turns a logic error into a counted abort instead of a hung GPU.
+// (a relaxed atomic load, not a volatile one: the compiler keeps a volatile access through a pointer
+// as a FLAT load, whose wait also waits for every outstanding global load of the wave)
+__device__ inline bool chain_wait_commit(const int *commits, int want)
+{
+    for (int spin = 0; spin < (1 << 22); spin++) {
+        if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(commits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) >= want) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+            return true;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    return false;
+}
+
 __global__ void __launch_bounds__(CH_THREADS)
 qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGeom bg, int bots_per_graph,
                      int max_agent, int win, int min_between, double r2thr, double corr,
@@ -275,29 +303,33 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
     const int bot0 = g * bots_per_graph + 1;
     const int nb = min(bots_per_graph, max_agent - bot0 + 1);
 
-    __shared__ double s_drift[QS_MAX_AGENT + 1][2];
-    __shared__ long long s_last[QS_MAX_AGENT + 1];
+    // drift and last closure of every agent as they stand at the START of a window, by window parity:
+    // during window V the owners read/write their registers and publish the state after V into
+    // [(V + 1) & 1], while wave 0 reads [V & 1] (commit of V - 1, prepare of V)
+    __shared__ double s_dx[2][QS_MAX_AGENT + 1], s_dy[2][QS_MAX_AGENT + 1];
+    __shared__ long long s_lastc[2][QS_MAX_AGENT + 1];
     __shared__ unsigned int s_acnt[QS_MAX_AGENT + 1];
     __shared__ long long w_ridx[32];            // query results of the window: matched landmark (node index, pose)
     __shared__ double w_rx[32], w_ry[32];
-    __shared__ long long n_idx[32];            // next window's events, prefetched by the last wave
-    __shared__ double n_px[32], n_py[32];
-    __shared__ int n_a[32], n_type[32];
+    __shared__ long long n_idx[2][32];          // events of the current window / the one after it (by parity)
+    __shared__ double n_px[2][32], n_py[2][32];
+    __shared__ int n_a[2][32], n_type[2][32];
     __shared__ long long i_idx[32], i_kb[32];   // the window just committed: its landmarks, final poses (inserted
     __shared__ double i_x[32], i_y[32];         // into the index by wave CH_INS during the next window's queries)
     __shared__ int i_type[32];
     __shared__ int s_ik;
     __shared__ long long s_nmisc;
+    __shared__ int s_commits;                   // windows committed so far
+    __shared__ int s_abort;
 
     for (int t = tid; t < nb; t += CH_THREADS) {
-        s_drift[t][0] = drift[2 * (bot0 + t)];
-        s_drift[t][1] = drift[2 * (bot0 + t) + 1];
-        s_last[t] = last_closure[bot0 + t];
-        s_acnt[t] = 0;
+        s_dx[0][t] = drift[2 * (bot0 + t)];
+        s_dy[0][t] = drift[2 * (bot0 + t) + 1];
+        s_lastc[0][t] = last_closure[bot0 + t];
+        s_acnt[t] = sb.agent_ev[bot0 + t];             // where the agent's next closure record goes
     }
-    if (tid == 0) { s_nmisc = G.n_misc; s_ik = 0; }
+    if (tid == 0) { s_nmisc = G.n_misc; s_ik = 0; s_commits = 0; s_abort = 0; }
     if (tid < 32) { i_idx[tid] = LL_MAX; i_kb[tid] = -1; i_x[tid] = 0; i_y[tid] = 0; i_type[tid] = 0; w_ridx[tid] = LL_MAX; }
-    __syncthreads();
 
     const unsigned int e0 = sb.ev_base[g], e1 = sb.ev_base[g + 1];
     long long n_cls = G.n_cls;                                         // authoritative in wave 0
@@ -307,95 +339,215 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
     unsigned long long st_windows = 0, st_rounds = 0, st_iters = 0, st_misc = 0, st_a = 0, st_b = 0, st_c = 0;
     const unsigned long long t0_cyc = __builtin_amdgcn_s_memtime(), t0_real = __builtin_amdgcn_s_memrealtime();
 
-    // registers of wave 0 that live across the phases of one window
-    long long idx = LL_MAX, kb = -1, first = 0;
-    int a = 0, type = 0;
-    double px = 0, py = 0, x = 0, y = 0;
-    unsigned int nbm = 0;
-    bool inw = false, elig = false;
-
     if (wave == CH_WAVES - 1 && lane < 32) {
         const bool have = e0 + lane < e1;
-        n_idx[lane] = have ? sb.ev_node[e0 + lane] : LL_MAX;
-        n_a[lane] = have ? sb.ev_agent[e0 + lane] : 0; n_type[lane] = have ? sb.ev_type[e0 + lane] : 0;
-        n_px[lane] = have ? sb.ev_px[e0 + lane] : 0; n_py[lane] = have ? sb.ev_py[e0 + lane] : 0;
+        n_idx[0][lane] = have ? sb.ev_node[e0 + lane] : LL_MAX;
+        n_a[0][lane] = have ? sb.ev_agent[e0 + lane] : 0; n_type[0][lane] = have ? sb.ev_type[e0 + lane] : 0;
+        n_px[0][lane] = have ? sb.ev_px[e0 + lane] : 0; n_py[0][lane] = have ? sb.ev_py[e0 + lane] : 0;
     }
     __syncthreads();
 
-    for (unsigned int e = e0; e < e1;) {
-        // ---- phase AB: the window = the next events whose node index is < first + win.  Every wave reads
-        // it from the prefetched events; then, side by side,
-        //   wave 0         poses ALL the window's events (for the commit and the index),
-        //   waves 1..CH_AGW each agent's owner finds that agent's first eligible event, poses just that one
-        //                  itself and queries it (then the next, until a match: only an agent's FIRST eligible
-        //                  event with a match closes the loop, :304-318) -- it does not wait for wave 0,
-        //   wave CH_INS    moves the window committed last into the index,
-        //   the last wave  fetches the events after this window. -------------------------------------------
+    // registers of wave 0: the window it prepared (committed one phase later)
+    long long idx = LL_MAX, kb = -1, first = 0;
+    int a = 0, type = 0, kprev = 0;
+    double px = 0, py = 0, x = 0, y = 0;
+    unsigned int nbm = 0;
+    bool inw = false;
+
+    // registers of query wave w (1..CH_AGW), lane j: drift and last closure of agent (w - 1) + CH_AGW * j --
+    // the authoritative copy; nothing else writes an agent's state
+    const bool agw = wave >= 1 && wave <= CH_AGW;
+    const QsNodeG g_nodes = (QsNodeG)G.nodes;
+    const QsDirG g_dir = (QsDirG)G.dir;
+    const QsU32G g_next = (QsU32G)G.nd_next;
+    const int own = agw ? (wave - 1) + CH_AGW * lane : nb;
+    double c_dx = 0, c_dy = 0;
+    long long c_last = 0;
+    if (own < nb) { c_dx = s_dx[0][own]; c_dy = s_dy[0][own]; c_last = s_lastc[0][own]; }
+
+    // ---- one phase per window, one barrier per phase.  In phase V, side by side:
+    //   wave 0          commits window V - 1 in node order (closure records, later events of a closing agent
+    //                   re-posed, landmarks handed to wave CH_INS), signals it, then poses ALL of window V's events
+    //   waves 1..CH_AGW each agent's owner finds the agent's first eligible event of window V, poses it, and
+    //                   scans the index for it AT ONCE -- the index holds everything up to window V - 2, and what
+    //                   a query needs of window V - 1 (its landmarks' final poses) it takes from LDS after the
+    //                   commit signal; then the agent's next event, until a match: only an agent's FIRST eligible
+    //                   event with a match closes the loop (:304-318).  The owner applies the closure to its
+    //                   agent's state itself: the arithmetic is wave 0's, on the same operands
+    //   wave CH_INS     after the commit signal, moves window V - 1 into the index
+    //   the last wave   fetches the events after window V. ------------------------------------------------------
+    unsigned int e = e0;
+    int par = 0, phase = 0;
+#ifdef QS_CHAIN_PROF
+    unsigned long long pq_a = 0, pq_b = 0, pq_c = 0;
+#endif
+#ifdef QS_CHAIN_PROF2
+    unsigned long long pl_a = 0, pl_b = 0;
+#endif
+    bool have_prev = false;
+    for (;; phase++) {
+        const bool active = e < e1;
+        if (!active && !have_prev) break;
         const unsigned long long ta0 = __builtin_amdgcn_s_memtime();
-        const bool have = lane < 32 && e + lane < e1;
-        const long long v_idx = have ? n_idx[lane] : LL_MAX;
-        const int v_a = have ? n_a[lane] : 0;
-        first = rl64(v_idx, 0);
-        const bool v_inw = have && v_idx < first + win;                 // a contiguous prefix of the lanes
+        // the window = the next events whose node index is < first + win (a contiguous prefix of the lanes)
+        const bool have = active && lane < 32 && e + lane < e1;
+        const long long v_idx = have ? n_idx[par][lane] : LL_MAX;
+        const int v_a = have ? n_a[par][lane] : 0;
+        const long long cur_first = rl64(v_idx, 0);
+        const bool v_inw = have && v_idx - cur_first < win;
         const int k = __popcll(__ballot(v_inw));
+
         if (wave == 0) {
-            idx = v_idx; a = v_a; type = 0; px = 0; py = 0;
-            if (have) { type = n_type[lane]; px = n_px[lane]; py = n_py[lane]; }
-            inw = v_inw;
-            if (!inw) { a = 0; type = 0; }
-            x = raw_pose ? px : px + s_drift[a][0];                 // rx += cdx  :856
-            y = raw_pose ? py : py + s_drift[a][1];                 // ry += cdy  :857
-            elig = inw && (idx - s_last[a] >= min_between);         // :304
-            bucket_prepare(x, y, type, bg, dir_slab, kb, nbm);
-            st_windows++;
+            if (have_prev) {
+                // ---- commit of window V - 1, in node order ----
+                const long long m_idx = lane < 32 ? w_ridx[lane] : LL_MAX;
+                const double m_x = lane < 32 ? w_rx[lane] : 0, m_y = lane < 32 ? w_ry[lane] : 0;
+                // the query phase stops an agent at its first match, so a result marks exactly the closing event
+                const bool closes = inw && m_idx != LL_MAX;
+                const unsigned long long cmask = __ballot(closes);
+                if (closes) {
+                    const double ex = m_x - x, ey = m_y - y;                                   // :311-312
+                    const double cdx = ex * corr, cdy = ey * corr;                             // :314-315
+                    const long long slot = n_cls + __popcll(cmask & ((1ull << lane) - 1));
+                    if (slot < G.cap_cls) {
+                        G.cl_lm_idx[slot] = m_idx; G.cl_node_idx[slot] = idx;                  // :317
+                        G.cl_dx[slot] = cdx; G.cl_dy[slot] = cdy;
+                    }
+                    const unsigned int pos = s_acnt[a];
+                    sb.acl_node[pos] = idx; sb.acl_dx[pos] = s_dx[par][a]; sb.acl_dy[pos] = s_dy[par][a];   // :911-914
+                    s_acnt[a] = pos + 1;
+                }
+                n_cls += __popcll(cmask);
+                if (cmask && !raw_pose && inw && !closes) {
+                    // later events of a closing agent in this window are posed (and stored) with the new drift
+                    const long long la = s_lastc[par][a];
+                    if (la >= first && la < idx) {
+                        x = px + s_dx[par][a];
+                        y = py + s_dy[par][a];
+                        bucket_prepare(x, y, type, bg, dir_slab, kb, nbm);
+                    }
+                }
+                // hand the window's landmarks (final poses) to wave CH_INS: self.landmarks.append(...)  :288
+                if (lane < 32) {
+                    i_idx[lane] = inw ? idx : LL_MAX; i_x[lane] = x; i_y[lane] = y; i_type[lane] = inw ? type : 0;
+                    i_kb[lane] = (inw && kb >= 0 && ((nbm >> 4) & 1u)) ? kb : -1;      // -1: not in the directory (side list)
+                    w_ridx[lane] = LL_MAX;                                             // no result yet for window V
+                }
+                if (lane == 0) s_ik = kprev;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+                if (lane == 0) __hip_atomic_store(&s_commits, phase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                st_a += __builtin_amdgcn_s_memtime() - ta0;
+            }
+            if (active) {
+                // ---- prepare window V: pose with the drift at window start, bucket key + 3x3 neighbour mask ----
+                idx = v_idx; a = v_a; type = 0; px = 0; py = 0;
+                if (have) { type = n_type[par][lane]; px = n_px[par][lane]; py = n_py[par][lane]; }
+                inw = v_inw;
+                if (!inw) { a = 0; type = 0; }
+                x = raw_pose ? px : px + s_dx[par][a];                  // rx += cdx  :856
+                y = raw_pose ? py : py + s_dy[par][a];                  // ry += cdy  :857
+                bucket_prepare(x, y, type, bg, dir_slab, kb, nbm);
+                first = cur_first; kprev = k;
+                st_windows++;
+            } else {
+                inw = false; kprev = 0;
+            }
         }
-        // the last wave fetches the next window's events while the queries run
-        long long f_idx = LL_MAX; int f_a = 0, f_type = 0; double f_px = 0, f_py = 0;
-        const bool fetcher = wave == CH_WAVES - 1 && lane < 32;
-        if (fetcher && e + k + lane < e1) {
+        // the last wave fetches the events after this window
+        if (wave == CH_WAVES - 1 && lane < 32 && active) {
             const unsigned int q = e + k + lane;
-            f_idx = sb.ev_node[q]; f_a = sb.ev_agent[q]; f_type = sb.ev_type[q]; f_px = sb.ev_px[q]; f_py = sb.ev_py[q];
+            long long f_idx = LL_MAX; int f_a = 0, f_type = 0; double f_px = 0, f_py = 0;
+            if (q < e1) { f_idx = sb.ev_node[q]; f_a = sb.ev_agent[q]; f_type = sb.ev_type[q]; f_px = sb.ev_px[q]; f_py = sb.ev_py[q]; }
+            n_idx[par ^ 1][lane] = f_idx; n_a[par ^ 1][lane] = f_a; n_type[par ^ 1][lane] = f_type;
+            n_px[par ^ 1][lane] = f_px; n_py[par ^ 1][lane] = f_py;
         }
-        // wave CH_INS moves the window committed last into the index while the queries run
-        if (wave == CH_INS && s_ik > 0) {
-            chain_insert_window(G, i_idx, i_kb, i_x, i_y, i_type, s_ik, lane, n_lms, n_misc, pool);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the stores are done before the phase ends ...
-            if (lane == 0) s_nmisc = n_misc;                         // ... and before the side list's new length shows
+        // wave CH_INS moves the window committed in this phase into the index
+        if (wave == CH_INS && have_prev) {
+            if (!chain_wait_commit(&s_commits, phase)) s_abort = 1;
+            if (s_ik > 0) {
+                chain_insert_window(G, i_idx, i_kb, i_x, i_y, i_type, s_ik, lane, n_lms, n_misc, pool);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the stores are done before the phase ends ...
+                if (lane == 0) s_nmisc = n_misc;                         // ... and before the side list's new length shows
+            }
         }
         // query waves.  lane = (bucket of the 3x3 neighbourhood, entry of that bucket's current 7-entry
         // node): a node scan is three coalesced row loads (idx, x, y of 9 nodes)
-        if (wave >= 1 && wave <= CH_AGW) {
+        if (agw && active) {
             unsigned int done = 0;                      // bit a / CH_AGW: agent a has its match
+            bool waited = !have_prev;
             for (unsigned long long qrem = __ballot(v_inw && (v_a % CH_AGW) + 1 == wave); qrem; qrem &= qrem - 1) {
+#ifdef QS_CHAIN_PROF
+                const unsigned long long tq0 = __builtin_amdgcn_s_memtime();
+#endif
                 const int src = __ffsll((long long)qrem) - 1;
                 const int qa = __builtin_amdgcn_readlane(v_a, src);
-                if ((done >> (qa / CH_AGW)) & 1u) continue;
+                const int ql = qa / CH_AGW;                                         // the lane that keeps agent qa's state
+                if ((done >> ql) & 1u) continue;
                 const long long qidx = rl64(v_idx, src);
-                if (qidx - s_last[qa] < min_between) continue;                      // :304
+                if (qidx - rl64(c_last, ql) < min_between) continue;                // :304
                 const int nbk = lane / QS_NODE_CAP, se = lane % QS_NODE_CAP;
                 const int last_lane = min(nbk * QS_NODE_CAP + QS_NODE_CAP - 1, 63);
-                const double qx = raw_pose ? n_px[src] : n_px[src] + s_drift[qa][0];   // rx += cdx  :856
-                const double qy = raw_pose ? n_py[src] : n_py[src] + s_drift[qa][1];   // ry += cdy  :857
-                const int qtype = n_type[src];
+                const double odx = rlf64(c_dx, ql), ody = rlf64(c_dy, ql);
+                const double qx = raw_pose ? n_px[par][src] : n_px[par][src] + odx;   // rx += cdx  :856
+                const double qy = raw_pose ? n_py[par][src] : n_py[par][src] + ody;   // ry += cdy  :857
+                const int qtype = n_type[par][src];
                 const long long limit = qidx - min_between;                        // :300
                 long long qkb; unsigned int qnbm;
                 bucket_prepare(qx, qy, qtype, bg, dir_slab, qkb, qnbm);
                 unsigned int node = 0;
                 if (lane < 9 * QS_NODE_CAP && ((qnbm >> nbk) & 1u))
-                    node = G.dir[qkb + ((nbk / 3) - 1) * (long long)bg.nbx + (nbk % 3) - 1].head;
+                    node = g_dir[qkb + ((nbk / 3) - 1) * (long long)bg.nbx + (nbk % 3) - 1].head;
                 long long best = LL_MAX, gbest = LL_MAX;
                 double bx = 0, by = 0;
                 st_rounds++;
-                while (__ballot(node != 0)) {
-                    st_iters++;
+#ifdef QS_CHAIN_PROF
+                const unsigned long long tq1 = __builtin_amdgcn_s_memtime();
+#endif
+#ifdef QS_CHAIN_PROF2
+                { const unsigned long long u0 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0); asm volatile("" :: "v"(node)); pl_a += __builtin_amdgcn_s_memtime() - u0; }
+#endif
+                // window V - 1 is not in the index yet: its landmarks (final poses) are in LDS, in node order,
+                // once wave 0 has committed it.  That scan runs in the shadow of the first node loads.
+                long long l_idx = LL_MAX, nm = 0;
+                double l_x = 0, l_y = 0;
+                for (bool lds_done = false;;) {
+                    const bool anyn = __ballot(node != 0) != 0;
                     long long id = LL_MAX;
                     double nx = 0, ny = 0;
                     unsigned int nxt = 0;
                     long long lastid = LL_MAX;                         // the node's last entry: same 64-byte row as `id`,
                     if (node) {                                         // read directly instead of a cross-lane shuffle
-                        const QsLmNode *nd = G.nodes + node;
-                        id = nd->idx[se]; lastid = nd->idx[QS_NODE_CAP - 1]; nx = nd->x[se]; ny = nd->y[se]; nxt = G.nd_next[node];
+                        const QsNodeG nd = g_nodes + node;
+                        id = nd->idx[se]; lastid = nd->idx[QS_NODE_CAP - 1]; nx = nd->x[se]; ny = nd->y[se]; nxt = g_next[node];
                     }
+#ifdef QS_CHAIN_PROF2
+                    { const unsigned long long u0 = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt vmcnt(0)" :: "v"(id), "v"(nx), "v"(ny), "v"(nxt), "v"(lastid)); pl_b += __builtin_amdgcn_s_memtime() - u0; }
+#endif
+                    if (!lds_done) {
+                        lds_done = true;
+                        if (!waited) {
+                            if (!chain_wait_commit(&s_commits, phase)) s_abort = 1;
+                            waited = true;
+                        }
+                        nm = s_nmisc;
+                        bool cand = false;
+                        long long li = LL_MAX; double lx = 0, ly = 0;
+                        if (lane < 32) {
+                            li = i_idx[lane];
+                            if (li <= limit && i_type[lane] == qtype) {
+                                lx = i_x[lane]; ly = i_y[lane];
+                                const double dx = qx - lx, dy = qy - ly;
+                                cand = dx * dx + dy * dy < r2thr;
+                            }
+                        }
+                        const unsigned long long cm = __ballot(cand);
+                        if (cm) {
+                            const int w = __ffsll((long long)cm) - 1;
+                            l_idx = rl64(li, w); l_x = rlf64(lx, w); l_y = rlf64(ly, w);
+                        }
+                    }
+                    if (!anyn) break;
+                    st_iters++;
                     const bool inlim = node != 0 && id <= limit;      // empty slots read as a huge index
                     bool newhit = false;
                     if (inlim && best == LL_MAX) {
@@ -414,13 +566,15 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
                     const bool b_full = ((limm >> last_lane) & 1ull) != 0;
                     if (node) node = (b_hit || !b_full || nxt == 0 || lastid >= gbest) ? 0u : nxt;
                 }
+#ifdef QS_CHAIN_PROF
+                const unsigned long long tq2 = __builtin_amdgcn_s_memtime();
+#endif
                 double wx = 0, wy = 0;
                 if (gbest != LL_MAX) {                                  // uniform
                     const int w = __ffsll((long long)__ballot(best == gbest)) - 1;
-                    wx = __shfl(bx, w); wy = __shfl(by, w);
+                    wx = rlf64(bx, w); wy = rlf64(by, w);
                 }
                 // landmarks outside the directory: linear scan in insertion order (rare)
-                const long long nm = s_nmisc;
                 for (long long c0 = 0; c0 < nm; c0 += QS_WAVE) {
                     st_misc++;
                     const long long k2 = c0 + lane;
@@ -440,109 +594,61 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
                     if (cm) {
                         const int w = __ffsll((long long)cm) - 1;
                         const long long widx = rl64(li, w);
-                        if (widx < gbest) { gbest = widx; wx = __shfl(lx, w); wy = __shfl(ly, w); }
+                        if (widx < gbest) { gbest = widx; wx = rlf64(lx, w); wy = rlf64(ly, w); }
                         break;
                     }
                     if (__ballot(beyond)) break;
                 }
-                // the window committed last is not in the index yet: its landmarks are in LDS, in node order
-                {
-                    bool cand = false;
-                    long long li = LL_MAX; double lx = 0, ly = 0;
-                    if (lane < 32) {
-                        li = i_idx[lane];
-                        if (li <= limit && i_type[lane] == qtype) {
-                            lx = i_x[lane]; ly = i_y[lane];
-                            const double dx = qx - lx, dy = qy - ly;
-                            cand = dx * dx + dy * dy < r2thr;
-                        }
-                    }
-                    const unsigned long long cm = __ballot(cand);
-                    if (cm) {
-                        const int w = __ffsll((long long)cm) - 1;
-                        const long long widx = rl64(li, w);
-                        if (widx < gbest) { gbest = widx; wx = __shfl(lx, w); wy = __shfl(ly, w); }
-                    }
-                }
+                if (l_idx < gbest) { gbest = l_idx; wx = l_x; wy = l_y; }
                 if (gbest != LL_MAX) {
-                    done |= 1u << (qa / CH_AGW);
+                    done |= 1u << ql;
                     if (lane == 0) { w_ridx[src] = gbest; w_rx[src] = wx; w_ry[src] = wy; }
+                    // the closure, applied to the agent's state by its owner (wave 0 writes the records)
+                    const double ex = wx - qx, ey = wy - qy;                                   // :311-312
+                    const double cdx = ex * corr, cdy = ey * corr;                             // :314-315
+                    if (lane == ql) { c_dx = odx + cdx; c_dy = ody + cdy; c_last = qidx; }     // :911-914, :318
                 }
+#ifdef QS_CHAIN_PROF
+                { const unsigned long long tq3 = __builtin_amdgcn_s_memtime(); pq_a += tq1 - tq0; pq_b += tq2 - tq1; pq_c += tq3 - tq2; }
+#endif
             }
         }
+        if (agw && active && own < nb) { s_dx[par ^ 1][own] = c_dx; s_dy[par ^ 1][own] = c_dy; s_lastc[par ^ 1][own] = c_last; }
         lds_barrier();
-        const unsigned long long tc0 = __builtin_amdgcn_s_memtime();
-        // (everyone has read this window's events: now the next ones may replace them)
-        if (fetcher) { n_idx[lane] = f_idx; n_a[lane] = f_a; n_type[lane] = f_type; n_px[lane] = f_px; n_py[lane] = f_py; }
-
-        // ---- phase C (wave 0): commit, in node order ------------------------------------------------------
-        if (wave == 0) {
-            const long long m_idx = lane < 32 ? w_ridx[lane] : LL_MAX;
-            const double m_x = lane < 32 ? w_rx[lane] : 0, m_y = lane < 32 ? w_ry[lane] : 0;
-            const bool matched = elig && m_idx != LL_MAX;
-            // per agent, its first eligible event with a match closes the loop: the query phase stops an
-            // agent at its first match, so a result marks exactly that event
-            const bool closes = matched;
-            const unsigned long long cmask = __ballot(closes);
-            if (closes) {
-                const double ex = m_x - x, ey = m_y - y;                                   // :311-312
-                const double cdx = ex * corr, cdy = ey * corr;                             // :314-315
-                const double ndx = s_drift[a][0] + cdx, ndy = s_drift[a][1] + cdy;         // :911-914
-                const long long slot = n_cls + __popcll(cmask & ((1ull << lane) - 1));
-                if (slot < G.cap_cls) {
-                    G.cl_lm_idx[slot] = m_idx; G.cl_node_idx[slot] = idx;                  // :317
-                    G.cl_dx[slot] = cdx; G.cl_dy[slot] = cdy;
-                }
-                const unsigned int pos = sb.agent_ev[bot0 + a] + s_acnt[a];
-                sb.acl_node[pos] = idx; sb.acl_dx[pos] = ndx; sb.acl_dy[pos] = ndy;
-                s_acnt[a] = s_acnt[a] + 1;
-                s_drift[a][0] = ndx; s_drift[a][1] = ndy;
-                s_last[a] = idx;                                                           // :318
-            }
-            n_cls += __popcll(cmask);
-            if (cmask) {
-                // later events of a closing agent in this window are posed (and stored) with the new drift
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-                if (!raw_pose && inw && !closes && s_last[a] >= first && s_last[a] < idx) {
-                    x = px + s_drift[a][0];
-                    y = py + s_drift[a][1];
-                    bucket_prepare(x, y, type, bg, dir_slab, kb, nbm);
-                }
-            }
-            // hand the window's landmarks (final poses) to wave CH_INS: self.landmarks.append(...)  :288
-            if (lane < 32) {
-                i_idx[lane] = inw ? idx : LL_MAX; i_x[lane] = x; i_y[lane] = y; i_type[lane] = inw ? type : 0;
-                i_kb[lane] = (inw && kb >= 0 && ((nbm >> 4) & 1u)) ? kb : -1;      // -1: not in the directory (side list)
-            }
-            if (lane == 0) s_ik = k;
-            if (lane < 32) w_ridx[lane] = LL_MAX;                    // no result yet for the next window
-        }
+        st_b += __builtin_amdgcn_s_memtime() - ta0;
         e += k;
-        // LDS hand-offs only: wave 0's closure records are read after the kernel, and the index stores of
-        // wave CH_INS were completed inside the query phase -- nothing here has to wait for HBM
-        lds_barrier();
-        st_b += tc0 - ta0; st_c += __builtin_amdgcn_s_memtime() - tc0;
+        have_prev = active;
+        if (active) par ^= 1;
+        if (s_abort) break;
     }
 
-    if (wave == CH_INS && s_ik > 0) chain_insert_window(G, i_idx, i_kb, i_x, i_y, i_type, s_ik, lane, n_lms, n_misc, pool);
-    for (int t = tid; t < nb; t += CH_THREADS) {
-        drift[2 * (bot0 + t)] = s_drift[t][0];
-        drift[2 * (bot0 + t) + 1] = s_drift[t][1];
-        last_closure[bot0 + t] = s_last[t];
-        sb.acl_cnt[bot0 + t] = s_acnt[t];
+    if (own < nb) {
+        drift[2 * (bot0 + own)] = c_dx;
+        drift[2 * (bot0 + own) + 1] = c_dy;
+        last_closure[bot0 + own] = c_last;
     }
+    for (int t = tid; t < nb; t += CH_THREADS) sb.acl_cnt[bot0 + t] = s_acnt[t] - sb.agent_ev[bot0 + t];
     // per-wave statistics, wave 0's bookkeeping
     if (lane == 0) {
         atomicAdd(&counters[QS_CNT_SLAM_ROUNDS], st_rounds);
         atomicAdd(&counters[QS_CNT_SLAM_NODE_ITERS], st_iters);
         atomicAdd(&counters[QS_CNT_SLAM_MISC_ITERS], st_misc);
+#ifdef QS_CHAIN_PROF
+        atomicAdd(&counters[QS_CNT_SLAM_CYC_A], pq_a); atomicAdd(&counters[QS_CNT_SLAM_CYC_B], pq_b); atomicAdd(&counters[QS_CNT_SLAM_CYC_C], pq_c);
+#endif
+#ifdef QS_CHAIN_PROF2
+        atomicAdd(&counters[QS_CNT_SLAM_CYC_A], pl_a); atomicAdd(&counters[QS_CNT_SLAM_CYC_B], pl_b);
+#endif
     }
     if (tid == 0) {
         atomicAdd(&counters[QS_CNT_CLOSURES], (unsigned long long)(n_cls - G.n_cls));
         atomicAdd(&counters[QS_CNT_SLAM_WINDOWS], st_windows);
+#if !defined(QS_CHAIN_PROF) && !defined(QS_CHAIN_PROF2)
         atomicAdd(&counters[QS_CNT_SLAM_CYC_A], st_a); atomicAdd(&counters[QS_CNT_SLAM_CYC_B], st_b); atomicAdd(&counters[QS_CNT_SLAM_CYC_C], st_c);
+#endif
         atomicAdd(&counters[QS_CNT_SLAM_CYCLES], __builtin_amdgcn_s_memtime() - t0_cyc);
         atomicAdd(&counters[QS_CNT_SLAM_REALTIME], __builtin_amdgcn_s_memrealtime() - t0_real);
+        if (s_abort) atomicAdd(&counters[QS_CNT_SLAM_ABORT], 1ull);
         graphs[g].n_nodes = G.n_nodes + sb.acc_total[g];
         graphs[g].n_cls = n_cls;
     }
