@@ -290,6 +290,38 @@ __device__ inline bool chain_wait_commit(const int *commits, int want)
     return false;
 }
 
+// the window at the head of the events: the next events whose node index is < first + win (a
+// contiguous prefix of the lanes).  Every role computes it for itself from the same LDS arrays.
+struct ChWindow { long long v_idx, first; int v_a, k; bool have, v_inw; };
+__device__ inline ChWindow chain_window(const long long *nidx, const int *na, bool active, unsigned int e, unsigned int e1,
+                                        int lane, int win)
+{
+    ChWindow w;
+    w.have = active && lane < 32 && e + lane < e1;
+    w.v_idx = w.have ? nidx[lane] : LL_MAX;
+    w.v_a = w.have ? na[lane] : 0;
+    w.first = rl64(w.v_idx, 0);
+    w.v_inw = w.have && w.v_idx - w.first < win;
+    w.k = __popcll(__ballot(w.v_inw));
+    return w;
+}
+
+// One workgroup per pose graph, one role per wave, one phase per window, one barrier per phase.  Each role
+// runs its OWN loop over the phases (the same count in every role: it follows from the events alone), so
+// that a role's loop keeps only that role's pointers and constants in registers.  In phase V, side by side:
+//   wave 0          writes the closure records of window V - 1 in node order, then poses ALL of window V's
+//                   events with the drift at window start and lays them out as the window's landmarks (LDS)
+//   waves 1..CH_AGW each agent's owner finds the agent's first eligible event of window V, poses it, and
+//                   scans the index for it -- the index holds everything up to window V - 2, window V - 1's
+//                   landmarks (final poses) are in LDS; then the agent's next event, until a match: only an
+//                   agent's FIRST eligible event with a match closes the loop (:304-318).  The owner applies
+//                   the closure itself (the arithmetic is wave 0's, on the same operands): to its agent's
+//                   state, and to the poses of the agent's later events in the window's landmarks
+//   wave CH_INS     moves window V - 1's landmarks into the index
+//   the last wave   fetches the events after window V.
+// Nothing inside a phase waits for another wave, except an owner that patches poses (it needs wave 0's
+// layout of the window: a flag it almost always finds set).
+// Waves without a role leave at once (a barrier counts the waves still running).
 __global__ void __launch_bounds__(CH_THREADS)
 qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGeom bg, int bots_per_graph,
                      int max_agent, int win, int min_between, double r2thr, double corr,
@@ -299,7 +331,7 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
     // raw_pose: poses are used as given (PoseGraphSLAM.add_pose object API: the caller has already
     // applied its drift correction, dual_bot_mapper.py:855-857 precede :908)
     const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    QsGraphDev G = graphs[g];
+    QsGraphDev *const Gp = graphs + g;
     const int bot0 = g * bots_per_graph + 1;
     const int nb = min(bots_per_graph, max_agent - bot0 + 1);
 
@@ -309,17 +341,17 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
     __shared__ double s_dx[2][QS_MAX_AGENT + 1], s_dy[2][QS_MAX_AGENT + 1];
     __shared__ long long s_lastc[2][QS_MAX_AGENT + 1];
     __shared__ unsigned int s_acnt[QS_MAX_AGENT + 1];
-    __shared__ long long w_ridx[32];            // query results of the window: matched landmark (node index, pose)
-    __shared__ double w_rx[32], w_ry[32];
+    __shared__ long long w_ridx[2][32];         // query results of a window: matched landmark (node index, pose)
+    __shared__ double w_rx[2][32], w_ry[2][32];
     __shared__ long long n_idx[2][32];          // events of the current window / the one after it (by parity)
     __shared__ double n_px[2][32], n_py[2][32];
     __shared__ int n_a[2][32], n_type[2][32];
-    __shared__ long long i_idx[32], i_kb[32];   // the window just committed: its landmarks, final poses (inserted
-    __shared__ double i_x[32], i_y[32];         // into the index by wave CH_INS during the next window's queries)
-    __shared__ int i_type[32];
-    __shared__ int s_ik;
+    __shared__ long long i_idx[2][32], i_kb[2][32];   // a window's landmarks (by window parity): node index, bucket,
+    __shared__ double i_x[2][32], i_y[2][32];         // pose.  Final at the end of the window's phase; read by the next
+    __shared__ int i_type[2][32];                     // window's queries and moved into the index by wave CH_INS
+    __shared__ int s_ik[2];
     __shared__ long long s_nmisc;
-    __shared__ int s_commits;                   // windows committed so far
+    __shared__ int s_prepared;                  // windows laid out by wave 0 so far
     __shared__ int s_abort;
 
     for (int t = tid; t < nb; t += CH_THREADS) {
@@ -328,16 +360,14 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
         s_lastc[0][t] = last_closure[bot0 + t];
         s_acnt[t] = sb.agent_ev[bot0 + t];             // where the agent's next closure record goes
     }
-    if (tid == 0) { s_nmisc = G.n_misc; s_ik = 0; s_commits = 0; s_abort = 0; }
-    if (tid < 32) { i_idx[tid] = LL_MAX; i_kb[tid] = -1; i_x[tid] = 0; i_y[tid] = 0; i_type[tid] = 0; w_ridx[tid] = LL_MAX; }
+    if (tid == 0) { s_nmisc = Gp->n_misc; s_ik[0] = 0; s_ik[1] = 0; s_prepared = 0; s_abort = 0; }
+    if (tid < 64) {
+        const int h = tid >> 5, t = tid & 31;
+        i_idx[h][t] = LL_MAX; i_kb[h][t] = -1; i_x[h][t] = 0; i_y[h][t] = 0; i_type[h][t] = 0; w_ridx[h][t] = LL_MAX;
+    }
 
     const unsigned int e0 = sb.ev_base[g], e1 = sb.ev_base[g + 1];
-    long long n_cls = G.n_cls;                                         // authoritative in wave 0
-    long long n_lms = G.n_lms, n_misc = G.n_misc;                      // authoritative in wave CH_INS
-    unsigned int pool = G.nodes_used;
     const long long dir_slab = (long long)bg.nbx * bg.nby;
-    unsigned long long st_windows = 0, st_rounds = 0, st_iters = 0, st_misc = 0, st_a = 0, st_b = 0, st_c = 0;
-    const unsigned long long t0_cyc = __builtin_amdgcn_s_memtime(), t0_real = __builtin_amdgcn_s_memrealtime();
 
     if (wave == CH_WAVES - 1 && lane < 32) {
         const bool have = e0 + lane < e1;
@@ -347,61 +377,34 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
     }
     __syncthreads();
 
-    // registers of wave 0: the window it prepared (committed one phase later)
-    long long idx = LL_MAX, kb = -1, first = 0;
-    int a = 0, type = 0, kprev = 0;
-    double px = 0, py = 0, x = 0, y = 0;
-    unsigned int nbm = 0;
-    bool inw = false;
-
-    // registers of query wave w (1..CH_AGW), lane j: drift and last closure of agent (w - 1) + CH_AGW * j --
-    // the authoritative copy; nothing else writes an agent's state
-    const bool agw = wave >= 1 && wave <= CH_AGW;
-    const QsNodeG g_nodes = (QsNodeG)G.nodes;
-    const QsDirG g_dir = (QsDirG)G.dir;
-    const QsU32G g_next = (QsU32G)G.nd_next;
-    const int own = agw ? (wave - 1) + CH_AGW * lane : nb;
-    double c_dx = 0, c_dy = 0;
-    long long c_last = 0;
-    if (own < nb) { c_dx = s_dx[0][own]; c_dy = s_dy[0][own]; c_last = s_lastc[0][own]; }
-
-    // ---- one phase per window, one barrier per phase.  In phase V, side by side:
-    //   wave 0          commits window V - 1 in node order (closure records, later events of a closing agent
-    //                   re-posed, landmarks handed to wave CH_INS), signals it, then poses ALL of window V's events
-    //   waves 1..CH_AGW each agent's owner finds the agent's first eligible event of window V, poses it, and
-    //                   scans the index for it AT ONCE -- the index holds everything up to window V - 2, and what
-    //                   a query needs of window V - 1 (its landmarks' final poses) it takes from LDS after the
-    //                   commit signal; then the agent's next event, until a match: only an agent's FIRST eligible
-    //                   event with a match closes the loop (:304-318).  The owner applies the closure to its
-    //                   agent's state itself: the arithmetic is wave 0's, on the same operands
-    //   wave CH_INS     after the commit signal, moves window V - 1 into the index
-    //   the last wave   fetches the events after window V. ------------------------------------------------------
     unsigned int e = e0;
     int par = 0, phase = 0;
-#ifdef QS_CHAIN_PROF
-    unsigned long long pq_a = 0, pq_b = 0, pq_c = 0;
-#endif
-#ifdef QS_CHAIN_PROF2
-    unsigned long long pl_a = 0, pl_b = 0;
-#endif
     bool have_prev = false;
-    for (;; phase++) {
-        const bool active = e < e1;
-        if (!active && !have_prev) break;
-        const unsigned long long ta0 = __builtin_amdgcn_s_memtime();
-        // the window = the next events whose node index is < first + win (a contiguous prefix of the lanes)
-        const bool have = active && lane < 32 && e + lane < e1;
-        const long long v_idx = have ? n_idx[par][lane] : LL_MAX;
-        const int v_a = have ? n_a[par][lane] : 0;
-        const long long cur_first = rl64(v_idx, 0);
-        const bool v_inw = have && v_idx - cur_first < win;
-        const int k = __popcll(__ballot(v_inw));
+// what every role does at the end of a phase (s_abort is read after the barrier: uniform)
+#define CH_PHASE_END(active_, k_)  lds_barrier(); e += (k_); have_prev = (active_); if (active_) par ^= 1; if (s_abort) break
 
-        if (wave == 0) {
+    if (wave == 0) {
+        // =================================== wave 0: commit + prepare ===================================
+        long long n_cls = Gp->n_cls;
+        const long long n_cls0 = n_cls, cap_cls = Gp->cap_cls;
+        long long *const cl_lm_idx = Gp->cl_lm_idx, *const cl_node_idx = Gp->cl_node_idx;
+        double *const cl_dx = Gp->cl_dx, *const cl_dy = Gp->cl_dy;
+        unsigned long long st_windows = 0, st_a = 0, st_b = 0;
+        const unsigned long long t0_cyc = __builtin_amdgcn_s_memtime(), t0_real = __builtin_amdgcn_s_memrealtime();
+        // the window it prepared (its closure records are written one phase later)
+        long long idx = LL_MAX;
+        int a = 0;
+        double x = 0, y = 0;
+        bool inw = false;
+        for (;; phase++) {
+            const bool active = e < e1;
+            if (!active && !have_prev) break;
+            const unsigned long long ta0 = __builtin_amdgcn_s_memtime();
+            const ChWindow W = chain_window(n_idx[par], n_a[par], active, e, e1, lane, win);
             if (have_prev) {
-                // ---- commit of window V - 1, in node order ----
-                const long long m_idx = lane < 32 ? w_ridx[lane] : LL_MAX;
-                const double m_x = lane < 32 ? w_rx[lane] : 0, m_y = lane < 32 ? w_ry[lane] : 0;
+                // ---- closure records of window V - 1, in node order ----
+                const long long m_idx = lane < 32 ? w_ridx[par ^ 1][lane] : LL_MAX;
+                const double m_x = lane < 32 ? w_rx[par ^ 1][lane] : 0, m_y = lane < 32 ? w_ry[par ^ 1][lane] : 0;
                 // the query phase stops an agent at its first match, so a result marks exactly the closing event
                 const bool closes = inw && m_idx != LL_MAX;
                 const unsigned long long cmask = __ballot(closes);
@@ -409,84 +412,132 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
                     const double ex = m_x - x, ey = m_y - y;                                   // :311-312
                     const double cdx = ex * corr, cdy = ey * corr;                             // :314-315
                     const long long slot = n_cls + __popcll(cmask & ((1ull << lane) - 1));
-                    if (slot < G.cap_cls) {
-                        G.cl_lm_idx[slot] = m_idx; G.cl_node_idx[slot] = idx;                  // :317
-                        G.cl_dx[slot] = cdx; G.cl_dy[slot] = cdy;
+                    if (slot < cap_cls) {
+                        cl_lm_idx[slot] = m_idx; cl_node_idx[slot] = idx;                      // :317
+                        cl_dx[slot] = cdx; cl_dy[slot] = cdy;
                     }
                     const unsigned int pos = s_acnt[a];
                     sb.acl_node[pos] = idx; sb.acl_dx[pos] = s_dx[par][a]; sb.acl_dy[pos] = s_dy[par][a];   // :911-914
                     s_acnt[a] = pos + 1;
                 }
                 n_cls += __popcll(cmask);
-                if (cmask && !raw_pose && inw && !closes) {
-                    // later events of a closing agent in this window are posed (and stored) with the new drift
-                    const long long la = s_lastc[par][a];
-                    if (la >= first && la < idx) {
-                        x = px + s_dx[par][a];
-                        y = py + s_dy[par][a];
-                        bucket_prepare(x, y, type, bg, dir_slab, kb, nbm);
-                    }
-                }
-                // hand the window's landmarks (final poses) to wave CH_INS: self.landmarks.append(...)  :288
-                if (lane < 32) {
-                    i_idx[lane] = inw ? idx : LL_MAX; i_x[lane] = x; i_y[lane] = y; i_type[lane] = inw ? type : 0;
-                    i_kb[lane] = (inw && kb >= 0 && ((nbm >> 4) & 1u)) ? kb : -1;      // -1: not in the directory (side list)
-                    w_ridx[lane] = LL_MAX;                                             // no result yet for window V
-                }
-                if (lane == 0) s_ik = kprev;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-                if (lane == 0) __hip_atomic_store(&s_commits, phase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (lane < 32) w_ridx[par ^ 1][lane] = LL_MAX;          // free for the window after this one
                 st_a += __builtin_amdgcn_s_memtime() - ta0;
             }
             if (active) {
-                // ---- prepare window V: pose with the drift at window start, bucket key + 3x3 neighbour mask ----
-                idx = v_idx; a = v_a; type = 0; px = 0; py = 0;
-                if (have) { type = n_type[par][lane]; px = n_px[par][lane]; py = n_py[par][lane]; }
-                inw = v_inw;
+                // ---- window V: pose with the drift at window start, bucket key + 3x3 neighbour mask; laid out
+                // as the window's landmarks: self.landmarks.append(...)  :288 ----
+                long long kb; unsigned int nbm;
+                int type = 0; double px = 0, py = 0;
+                idx = W.v_idx; a = W.v_a;
+                if (W.have) { type = n_type[par][lane]; px = n_px[par][lane]; py = n_py[par][lane]; }
+                inw = W.v_inw;
                 if (!inw) { a = 0; type = 0; }
                 x = raw_pose ? px : px + s_dx[par][a];                  // rx += cdx  :856
                 y = raw_pose ? py : py + s_dy[par][a];                  // ry += cdy  :857
                 bucket_prepare(x, y, type, bg, dir_slab, kb, nbm);
-                first = cur_first; kprev = k;
+                if (lane < 32) {
+                    i_idx[par][lane] = inw ? idx : LL_MAX; i_x[par][lane] = x; i_y[par][lane] = y; i_type[par][lane] = type;
+                    i_kb[par][lane] = (inw && kb >= 0 && ((nbm >> 4) & 1u)) ? kb : -1;      // -1: not in the directory (side list)
+                }
+                if (lane == 0) s_ik[par] = W.k;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+                if (lane == 0) __hip_atomic_store(&s_prepared, phase + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 st_windows++;
             } else {
-                inw = false; kprev = 0;
+                inw = false;
             }
+            CH_PHASE_END(active, W.k);
+            st_b += __builtin_amdgcn_s_memtime() - ta0;
         }
-        // the last wave fetches the events after this window
-        if (wave == CH_WAVES - 1 && lane < 32 && active) {
-            const unsigned int q = e + k + lane;
-            long long f_idx = LL_MAX; int f_a = 0, f_type = 0; double f_px = 0, f_py = 0;
-            if (q < e1) { f_idx = sb.ev_node[q]; f_a = sb.ev_agent[q]; f_type = sb.ev_type[q]; f_px = sb.ev_px[q]; f_py = sb.ev_py[q]; }
-            n_idx[par ^ 1][lane] = f_idx; n_a[par ^ 1][lane] = f_a; n_type[par ^ 1][lane] = f_type;
-            n_px[par ^ 1][lane] = f_px; n_py[par ^ 1][lane] = f_py;
+        if (lane == 0) {
+            atomicAdd(&counters[QS_CNT_CLOSURES], (unsigned long long)(n_cls - n_cls0));
+            atomicAdd(&counters[QS_CNT_SLAM_WINDOWS], st_windows);
+#if !defined(QS_CHAIN_PROF) && !defined(QS_CHAIN_PROF3)
+            atomicAdd(&counters[QS_CNT_SLAM_CYC_A], st_a); atomicAdd(&counters[QS_CNT_SLAM_CYC_B], st_b);
+#endif
+            atomicAdd(&counters[QS_CNT_SLAM_CYCLES], __builtin_amdgcn_s_memtime() - t0_cyc);
+            atomicAdd(&counters[QS_CNT_SLAM_REALTIME], __builtin_amdgcn_s_memrealtime() - t0_real);
+            if (s_abort) atomicAdd(&counters[QS_CNT_SLAM_ABORT], 1ull);
+            Gp->n_nodes = Gp->n_nodes + sb.acc_total[g];
+            Gp->n_cls = n_cls;
         }
-        // wave CH_INS moves the window committed in this phase into the index
-        if (wave == CH_INS && have_prev) {
-            if (!chain_wait_commit(&s_commits, phase)) s_abort = 1;
-            if (s_ik > 0) {
-                chain_insert_window(G, i_idx, i_kb, i_x, i_y, i_type, s_ik, lane, n_lms, n_misc, pool);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the stores are done before the phase ends ...
-                if (lane == 0) s_nmisc = n_misc;                         // ... and before the side list's new length shows
+        for (int t = lane; t < nb; t += QS_WAVE) sb.acl_cnt[bot0 + t] = s_acnt[t] - sb.agent_ev[bot0 + t];
+    } else if (wave == CH_WAVES - 1) {
+        // =================================== the last wave: event fetch ===================================
+        for (;; phase++) {
+            const bool active = e < e1;
+            if (!active && !have_prev) break;
+            const ChWindow W = chain_window(n_idx[par], n_a[par], active, e, e1, lane, win);
+            if (lane < 32 && active) {
+                const unsigned int q = e + W.k + lane;
+                long long f_idx = LL_MAX; int f_a = 0, f_type = 0; double f_px = 0, f_py = 0;
+                if (q < e1) { f_idx = sb.ev_node[q]; f_a = sb.ev_agent[q]; f_type = sb.ev_type[q]; f_px = sb.ev_px[q]; f_py = sb.ev_py[q]; }
+                n_idx[par ^ 1][lane] = f_idx; n_a[par ^ 1][lane] = f_a; n_type[par ^ 1][lane] = f_type;
+                n_px[par ^ 1][lane] = f_px; n_py[par ^ 1][lane] = f_py;
             }
+            CH_PHASE_END(active, W.k);
         }
-        // query waves.  lane = (bucket of the 3x3 neighbourhood, entry of that bucket's current 7-entry
-        // node): a node scan is three coalesced row loads (idx, x, y of 9 nodes)
-        if (agw && active) {
+    } else if (wave == CH_INS) {
+        // =================================== wave CH_INS: index insert ===================================
+        const QsGraphDev G = *Gp;
+        long long n_lms = G.n_lms, n_misc = G.n_misc;
+        unsigned int pool = G.nodes_used;
+        for (;; phase++) {
+            const bool active = e < e1;
+            if (!active && !have_prev) break;
+            const ChWindow W = chain_window(n_idx[par], n_a[par], active, e, e1, lane, win);
+            if (have_prev) {
+                if (s_ik[par ^ 1] > 0) {
+                    chain_insert_window(G, i_idx[par ^ 1], i_kb[par ^ 1], i_x[par ^ 1], i_y[par ^ 1], i_type[par ^ 1], s_ik[par ^ 1], lane,
+                                        n_lms, n_misc, pool);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the stores are done before the phase ends ...
+                    if (lane == 0) s_nmisc = n_misc;                         // ... and before the side list's new length shows
+                }
+            }
+            CH_PHASE_END(active, W.k);
+        }
+        if (lane == 0) {
+            atomicAdd(&counters[QS_CNT_LANDMARKS], (unsigned long long)(n_lms - G.n_lms));
+            Gp->n_lms = n_lms;
+            Gp->n_misc = n_misc;
+            Gp->nodes_used = pool;
+        }
+    } else if (wave >= 1 && wave <= CH_AGW && wave - 1 < nb) {
+        // =================================== query waves ===================================
+        // lane j keeps drift and last closure of agent (wave - 1) + CH_AGW * j -- the authoritative copy;
+        // nothing else writes an agent's state
+        const int own = (wave - 1) + CH_AGW * lane;
+        double c_dx = 0, c_dy = 0;
+        long long c_last = 0;
+        if (own < nb) { c_dx = s_dx[0][own]; c_dy = s_dy[0][own]; c_last = s_lastc[0][own]; }
+        const QsNodeG g_nodes = (QsNodeG)Gp->nodes;
+        const QsDirG g_dir = (QsDirG)Gp->dir;
+        const QsU32G g_next = (QsU32G)Gp->nd_next;
+        // lane = (bucket of the 3x3 neighbourhood, entry of that bucket's current 7-entry node): a node
+        // scan is three coalesced row loads (idx, x, y of 9 nodes)
+        const int nbk = lane / QS_NODE_CAP, se = lane % QS_NODE_CAP;
+        const int last_lane = min(nbk * QS_NODE_CAP + QS_NODE_CAP - 1, 63);
+        const long long nb_off = ((nbk / 3) - 1) * (long long)bg.nbx + (nbk % 3) - 1;
+        unsigned long long st_rounds = 0, st_iters = 0, st_misc = 0;
+#if defined(QS_CHAIN_PROF) || defined(QS_CHAIN_PROF3)
+        unsigned long long pq_a = 0, pq_b = 0, pq_c = 0, pq_d = 0;
+#endif
+        for (;; phase++) {
+            const bool active = e < e1;
+            if (!active && !have_prev) break;
+            const ChWindow W = chain_window(n_idx[par], n_a[par], active, e, e1, lane, win);
             unsigned int done = 0;                      // bit a / CH_AGW: agent a has its match
-            bool waited = !have_prev;
-            for (unsigned long long qrem = __ballot(v_inw && (v_a % CH_AGW) + 1 == wave); qrem; qrem &= qrem - 1) {
+            for (unsigned long long qrem = __ballot(W.v_inw && (W.v_a % CH_AGW) + 1 == wave); qrem; qrem &= qrem - 1) {
 #ifdef QS_CHAIN_PROF
                 const unsigned long long tq0 = __builtin_amdgcn_s_memtime();
 #endif
                 const int src = __ffsll((long long)qrem) - 1;
-                const int qa = __builtin_amdgcn_readlane(v_a, src);
+                const int qa = __builtin_amdgcn_readlane(W.v_a, src);
                 const int ql = qa / CH_AGW;                                         // the lane that keeps agent qa's state
                 if ((done >> ql) & 1u) continue;
-                const long long qidx = rl64(v_idx, src);
+                const long long qidx = rl64(W.v_idx, src);
                 if (qidx - rl64(c_last, ql) < min_between) continue;                // :304
-                const int nbk = lane / QS_NODE_CAP, se = lane % QS_NODE_CAP;
-                const int last_lane = min(nbk * QS_NODE_CAP + QS_NODE_CAP - 1, 63);
                 const double odx = rlf64(c_dx, ql), ody = rlf64(c_dy, ql);
                 const double qx = raw_pose ? n_px[par][src] : n_px[par][src] + odx;   // rx += cdx  :856
                 const double qy = raw_pose ? n_py[par][src] : n_py[par][src] + ody;   // ry += cdy  :857
@@ -495,22 +546,21 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
                 long long qkb; unsigned int qnbm;
                 bucket_prepare(qx, qy, qtype, bg, dir_slab, qkb, qnbm);
                 unsigned int node = 0;
-                if (lane < 9 * QS_NODE_CAP && ((qnbm >> nbk) & 1u))
-                    node = g_dir[qkb + ((nbk / 3) - 1) * (long long)bg.nbx + (nbk % 3) - 1].head;
+                if (lane < 9 * QS_NODE_CAP && ((qnbm >> nbk) & 1u)) node = g_dir[qkb + nb_off].head;
                 long long best = LL_MAX, gbest = LL_MAX;
                 double bx = 0, by = 0;
                 st_rounds++;
 #ifdef QS_CHAIN_PROF
                 const unsigned long long tq1 = __builtin_amdgcn_s_memtime();
 #endif
-#ifdef QS_CHAIN_PROF2
-                { const unsigned long long u0 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0); asm volatile("" :: "v"(node)); pl_a += __builtin_amdgcn_s_memtime() - u0; }
-#endif
-                // window V - 1 is not in the index yet: its landmarks (final poses) are in LDS, in node order,
-                // once wave 0 has committed it.  That scan runs in the shadow of the first node loads.
+                // window V - 1 is not in the index yet: its landmarks (final poses) are in LDS, in node order.
+                // That scan runs in the shadow of the first node loads.
                 long long l_idx = LL_MAX, nm = 0;
                 double l_x = 0, l_y = 0;
                 for (bool lds_done = false;;) {
+#ifdef QS_CHAIN_PROF3
+                    const unsigned long long u0 = __builtin_amdgcn_s_memtime();
+#endif
                     const bool anyn = __ballot(node != 0) != 0;
                     long long id = LL_MAX;
                     double nx = 0, ny = 0;
@@ -520,22 +570,18 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
                         const QsNodeG nd = g_nodes + node;
                         id = nd->idx[se]; lastid = nd->idx[QS_NODE_CAP - 1]; nx = nd->x[se]; ny = nd->y[se]; nxt = g_next[node];
                     }
-#ifdef QS_CHAIN_PROF2
-                    { const unsigned long long u0 = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt vmcnt(0)" :: "v"(id), "v"(nx), "v"(ny), "v"(nxt), "v"(lastid)); pl_b += __builtin_amdgcn_s_memtime() - u0; }
+#ifdef QS_CHAIN_PROF3
+                    const unsigned long long u1 = __builtin_amdgcn_s_memtime();
 #endif
                     if (!lds_done) {
                         lds_done = true;
-                        if (!waited) {
-                            if (!chain_wait_commit(&s_commits, phase)) s_abort = 1;
-                            waited = true;
-                        }
                         nm = s_nmisc;
                         bool cand = false;
                         long long li = LL_MAX; double lx = 0, ly = 0;
                         if (lane < 32) {
-                            li = i_idx[lane];
-                            if (li <= limit && i_type[lane] == qtype) {
-                                lx = i_x[lane]; ly = i_y[lane];
+                            li = i_idx[par ^ 1][lane];
+                            if (li <= limit && i_type[par ^ 1][lane] == qtype) {
+                                lx = i_x[par ^ 1][lane]; ly = i_y[par ^ 1][lane];
                                 const double dx = qx - lx, dy = qy - ly;
                                 cand = dx * dx + dy * dy < r2thr;
                             }
@@ -546,6 +592,12 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
                             l_idx = rl64(li, w); l_x = rlf64(lx, w); l_y = rlf64(ly, w);
                         }
                     }
+#ifdef QS_CHAIN_PROF3
+                    const unsigned long long u2 = __builtin_amdgcn_s_memtime();
+                    asm volatile("s_waitcnt vmcnt(0)" :: "v"(id), "v"(nx), "v"(ny), "v"(nxt), "v"(lastid));
+                    const unsigned long long u3 = __builtin_amdgcn_s_memtime();
+                    pq_a += u1 - u0; pq_b += u2 - u1; pq_c += u3 - u2;
+#endif
                     if (!anyn) break;
                     st_iters++;
                     const bool inlim = node != 0 && id <= limit;      // empty slots read as a huge index
@@ -554,9 +606,13 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
                         const double dx = qx - nx, dy = qy - ny;
                         if (dx * dx + dy * dy < r2thr) { best = id; bx = nx; by = ny; newhit = true; }   // :308-309
                     }
-                    for (unsigned long long hm = __ballot(newhit); hm; hm &= hm - 1) {
-                        const long long v = rl64(best, __ffsll((long long)hm) - 1);
+                    // a node's entries are in node order, so the first lane of a bucket's group that hits holds the
+                    // group's lowest index: at most 9 candidates, however many landmarks are within the radius
+                    for (unsigned long long hm = __ballot(newhit); hm;) {
+                        const int hl = __ffsll((long long)hm) - 1;
+                        const long long v = rl64(best, hl);
                         gbest = v < gbest ? v : gbest;
+                        hm &= ~(0x7full << ((hl / QS_NODE_CAP) * QS_NODE_CAP));
                     }
                     const unsigned long long hitm = __ballot(best != LL_MAX);
                     const unsigned long long limm = __ballot(inlim);
@@ -565,6 +621,9 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
                     const bool b_hit = ((hitm >> (nbk * QS_NODE_CAP)) & 0x7full) != 0;
                     const bool b_full = ((limm >> last_lane) & 1ull) != 0;
                     if (node) node = (b_hit || !b_full || nxt == 0 || lastid >= gbest) ? 0u : nxt;
+#ifdef QS_CHAIN_PROF3
+                    pq_d += __builtin_amdgcn_s_memtime() - u3;
+#endif
                 }
 #ifdef QS_CHAIN_PROF
                 const unsigned long long tq2 = __builtin_amdgcn_s_memtime();
@@ -575,89 +634,81 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
                     wx = rlf64(bx, w); wy = rlf64(by, w);
                 }
                 // landmarks outside the directory: linear scan in insertion order (rare)
-                for (long long c0 = 0; c0 < nm; c0 += QS_WAVE) {
-                    st_misc++;
-                    const long long k2 = c0 + lane;
-                    bool cand = false, beyond = false;
-                    long long li = LL_MAX; double lx = 0, ly = 0;
-                    if (k2 < nm) {
-                        const unsigned int slot = G.misc[k2];
-                        li = G.lm_idx[slot];
-                        beyond = li > limit;
-                        if (!beyond && G.lm_type[slot] == qtype) {
-                            lx = G.lm_x[slot]; ly = G.lm_y[slot];
-                            const double dx = qx - lx, dy = qy - ly;
-                            cand = dx * dx + dy * dy < r2thr;
+                if (nm > 0) {
+                    const unsigned int *const misc = Gp->misc;
+                    const long long *const lm_idx = Gp->lm_idx;
+                    const unsigned char *const lm_type = Gp->lm_type;
+                    const double *const lm_x = Gp->lm_x, *const lm_y = Gp->lm_y;
+                    for (long long c0 = 0; c0 < nm; c0 += QS_WAVE) {
+                        st_misc++;
+                        const long long k2 = c0 + lane;
+                        bool cand = false, beyond = false;
+                        long long li = LL_MAX; double lx = 0, ly = 0;
+                        if (k2 < nm) {
+                            const unsigned int slot = misc[k2];
+                            li = lm_idx[slot];
+                            beyond = li > limit;
+                            if (!beyond && lm_type[slot] == qtype) {
+                                lx = lm_x[slot]; ly = lm_y[slot];
+                                const double dx = qx - lx, dy = qy - ly;
+                                cand = dx * dx + dy * dy < r2thr;
+                            }
                         }
+                        const unsigned long long cm = __ballot(cand);
+                        if (cm) {
+                            const int w = __ffsll((long long)cm) - 1;
+                            const long long widx = rl64(li, w);
+                            if (widx < gbest) { gbest = widx; wx = rlf64(lx, w); wy = rlf64(ly, w); }
+                            break;
+                        }
+                        if (__ballot(beyond)) break;
                     }
-                    const unsigned long long cm = __ballot(cand);
-                    if (cm) {
-                        const int w = __ffsll((long long)cm) - 1;
-                        const long long widx = rl64(li, w);
-                        if (widx < gbest) { gbest = widx; wx = rlf64(lx, w); wy = rlf64(ly, w); }
-                        break;
-                    }
-                    if (__ballot(beyond)) break;
                 }
                 if (l_idx < gbest) { gbest = l_idx; wx = l_x; wy = l_y; }
                 if (gbest != LL_MAX) {
                     done |= 1u << ql;
-                    if (lane == 0) { w_ridx[src] = gbest; w_rx[src] = wx; w_ry[src] = wy; }
+                    if (lane == 0) { w_ridx[par][src] = gbest; w_rx[par][src] = wx; w_ry[par][src] = wy; }
                     // the closure, applied to the agent's state by its owner (wave 0 writes the records)
                     const double ex = wx - qx, ey = wy - qy;                                   // :311-312
                     const double cdx = ex * corr, cdy = ey * corr;                             // :314-315
-                    if (lane == ql) { c_dx = odx + cdx; c_dy = ody + cdy; c_last = qidx; }     // :911-914, :318
+                    const double ndx = odx + cdx, ndy = ody + cdy;                             // :911-914
+                    if (lane == ql) { c_dx = ndx; c_dy = ndy; c_last = qidx; }                 // :318
+                    // later events of the agent in this window are posed (and stored) with the new drift
+                    const bool later = !raw_pose && W.v_inw && W.v_a == qa && W.v_idx > qidx;
+                    if (__ballot(later)) {
+                        if (!chain_wait_commit(&s_prepared, phase + 1)) s_abort = 1;          // wave 0's layout first
+                        if (later) {
+                            const double lx = n_px[par][lane] + ndx, ly = n_py[par][lane] + ndy;
+                            long long lkb; unsigned int lnbm;
+                            bucket_prepare(lx, ly, n_type[par][lane], bg, dir_slab, lkb, lnbm);
+                            i_x[par][lane] = lx; i_y[par][lane] = ly;
+                            i_kb[par][lane] = (lkb >= 0 && ((lnbm >> 4) & 1u)) ? lkb : -1;
+                        }
+                    }
                 }
 #ifdef QS_CHAIN_PROF
                 { const unsigned long long tq3 = __builtin_amdgcn_s_memtime(); pq_a += tq1 - tq0; pq_b += tq2 - tq1; pq_c += tq3 - tq2; }
 #endif
             }
+            if (active && own < nb) { s_dx[par ^ 1][own] = c_dx; s_dy[par ^ 1][own] = c_dy; s_lastc[par ^ 1][own] = c_last; }
+            CH_PHASE_END(active, W.k);
         }
-        if (agw && active && own < nb) { s_dx[par ^ 1][own] = c_dx; s_dy[par ^ 1][own] = c_dy; s_lastc[par ^ 1][own] = c_last; }
-        lds_barrier();
-        st_b += __builtin_amdgcn_s_memtime() - ta0;
-        e += k;
-        have_prev = active;
-        if (active) par ^= 1;
-        if (s_abort) break;
-    }
-
-    if (own < nb) {
-        drift[2 * (bot0 + own)] = c_dx;
-        drift[2 * (bot0 + own) + 1] = c_dy;
-        last_closure[bot0 + own] = c_last;
-    }
-    for (int t = tid; t < nb; t += CH_THREADS) sb.acl_cnt[bot0 + t] = s_acnt[t] - sb.agent_ev[bot0 + t];
-    // per-wave statistics, wave 0's bookkeeping
-    if (lane == 0) {
-        atomicAdd(&counters[QS_CNT_SLAM_ROUNDS], st_rounds);
-        atomicAdd(&counters[QS_CNT_SLAM_NODE_ITERS], st_iters);
-        atomicAdd(&counters[QS_CNT_SLAM_MISC_ITERS], st_misc);
-#ifdef QS_CHAIN_PROF
-        atomicAdd(&counters[QS_CNT_SLAM_CYC_A], pq_a); atomicAdd(&counters[QS_CNT_SLAM_CYC_B], pq_b); atomicAdd(&counters[QS_CNT_SLAM_CYC_C], pq_c);
+        if (own < nb) {
+            drift[2 * (bot0 + own)] = c_dx;
+            drift[2 * (bot0 + own) + 1] = c_dy;
+            last_closure[bot0 + own] = c_last;
+        }
+        if (lane == 0) {
+            atomicAdd(&counters[QS_CNT_SLAM_ROUNDS], st_rounds);
+            atomicAdd(&counters[QS_CNT_SLAM_NODE_ITERS], st_iters);
+            atomicAdd(&counters[QS_CNT_SLAM_MISC_ITERS], st_misc);
+#if defined(QS_CHAIN_PROF) || defined(QS_CHAIN_PROF3)
+            atomicAdd(&counters[QS_CNT_SLAM_CYC_A], pq_a); atomicAdd(&counters[QS_CNT_SLAM_CYC_B], pq_b); atomicAdd(&counters[QS_CNT_SLAM_CYC_C], pq_c);
+            atomicAdd(&counters[QS_CNT_SLAM_MISC_ITERS], pq_d);
 #endif
-#ifdef QS_CHAIN_PROF2
-        atomicAdd(&counters[QS_CNT_SLAM_CYC_A], pl_a); atomicAdd(&counters[QS_CNT_SLAM_CYC_B], pl_b);
-#endif
+        }
     }
-    if (tid == 0) {
-        atomicAdd(&counters[QS_CNT_CLOSURES], (unsigned long long)(n_cls - G.n_cls));
-        atomicAdd(&counters[QS_CNT_SLAM_WINDOWS], st_windows);
-#if !defined(QS_CHAIN_PROF) && !defined(QS_CHAIN_PROF2)
-        atomicAdd(&counters[QS_CNT_SLAM_CYC_A], st_a); atomicAdd(&counters[QS_CNT_SLAM_CYC_B], st_b); atomicAdd(&counters[QS_CNT_SLAM_CYC_C], st_c);
-#endif
-        atomicAdd(&counters[QS_CNT_SLAM_CYCLES], __builtin_amdgcn_s_memtime() - t0_cyc);
-        atomicAdd(&counters[QS_CNT_SLAM_REALTIME], __builtin_amdgcn_s_memrealtime() - t0_real);
-        if (s_abort) atomicAdd(&counters[QS_CNT_SLAM_ABORT], 1ull);
-        graphs[g].n_nodes = G.n_nodes + sb.acc_total[g];
-        graphs[g].n_cls = n_cls;
-    }
-    if (wave == CH_INS && lane == 0) {
-        atomicAdd(&counters[QS_CNT_LANDMARKS], (unsigned long long)(n_lms - G.n_lms));
-        graphs[g].n_lms = n_lms;
-        graphs[g].n_misc = n_misc;
-        graphs[g].nodes_used = pool;
-    }
+#undef CH_PHASE_END
 }
 
 // ---- pose: rx, ry of every accepted record (dual_bot_mapper.py:855-857) ---------------------------

@@ -18,4 +18,4 @@ c = m.counters(); st = m.stage_times()
 w = c["slam_windows"]
 print(json.dumps({"windows": w, "slam_ms": st["slam"][0] / max(st["slam"][1], 1), "cyc_per_window": c["slam_cycles"] / w,
                   "A": c["slam_cyc_prepare"] / w, "B": c["slam_cyc_query"] / w, "C": c["slam_cyc_commit"] / w,
-                  "rounds": c["slam_rounds"] / w, "node_iters": c["slam_node_iters"] / w}))
+                  "rounds": c["slam_rounds"] / w, "node_iters": c["slam_node_iters"] / w, "misc": c["slam_misc_iters"] / w}))
