@@ -273,6 +273,30 @@ typedef const QS_GLOBAL unsigned int *QsU32G;
 // wave-uniform read of one lane of a double
 __device__ inline double rlf64(double v, int src_lane) { return __longlong_as_double(rl64(__double_as_longlong(v), src_lane)); }
 
+// minimum over the wave of an unsigned value, by DPP (no LDS, no loop over lanes): an inclusive min-scan
+// inside each row of 16 lanes, then lane 15 of rows 0/2 into rows 1/3, then lane 31 into rows 2/3
+__device__ inline unsigned int wave_min_u32(unsigned int v)
+{
+#define QS_DPP_MIN(ctrl, rows) v = min(v, (unsigned int)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)v, ctrl, rows, 0xf, false))
+    QS_DPP_MIN(0x111, 0xf);     // row_shr:1
+    QS_DPP_MIN(0x112, 0xf);     // row_shr:2
+    QS_DPP_MIN(0x114, 0xf);     // row_shr:4
+    QS_DPP_MIN(0x118, 0xf);     // row_shr:8
+    QS_DPP_MIN(0x142, 0xa);     // row_bcast:15
+    QS_DPP_MIN(0x143, 0xc);     // row_bcast:31
+#undef QS_DPP_MIN
+    return (unsigned int)__builtin_amdgcn_readlane((int)v, 63);
+}
+// minimum over the wave of a non-negative 64-bit value: high words first, then the low words of the
+// lanes that hold the lowest high word
+__device__ inline long long wave_min_nonneg_i64(long long v)
+{
+    const unsigned int hi = (unsigned int)((unsigned long long)v >> 32), lo = (unsigned int)v;
+    const unsigned int mhi = wave_min_u32(hi);
+    const unsigned int mlo = wave_min_u32(hi == mhi ? lo : 0xffffffffu);
+    return (long long)(((unsigned long long)mhi << 32) | mlo);
+}
+
 // wait until the commits counter (LDS) reaches `want`.  The writer (wave 0) sets it unconditionally, in
 // program order, before it reaches the phase's barrier, and no waiter holds anything wave 0 needs: the
 // wait cannot cycle.  The bound only turns a logic error into a counted abort instead of a hung GPU.
@@ -353,6 +377,9 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
     __shared__ long long s_nmisc;
     __shared__ int s_prepared;                  // windows laid out by wave 0 so far
     __shared__ int s_abort;
+#ifdef QS_CHAIN_PROF4
+    __shared__ unsigned int s_qcnt;
+#endif
 
     for (int t = tid; t < nb; t += CH_THREADS) {
         s_dx[0][t] = drift[2 * (bot0 + t)];
@@ -360,6 +387,9 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
         s_lastc[0][t] = last_closure[bot0 + t];
         s_acnt[t] = sb.agent_ev[bot0 + t];             // where the agent's next closure record goes
     }
+#ifdef QS_CHAIN_PROF4
+    if (tid == 0) s_qcnt = 0;
+#endif
     if (tid == 0) { s_nmisc = Gp->n_misc; s_ik[0] = 0; s_ik[1] = 0; s_prepared = 0; s_abort = 0; }
     if (tid < 64) {
         const int h = tid >> 5, t = tid & 31;
@@ -390,6 +420,9 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
         long long *const cl_lm_idx = Gp->cl_lm_idx, *const cl_node_idx = Gp->cl_node_idx;
         double *const cl_dx = Gp->cl_dx, *const cl_dy = Gp->cl_dy;
         unsigned long long st_windows = 0, st_a = 0, st_b = 0;
+#ifdef QS_CHAIN_PROF4
+        unsigned int q_prev = 0; unsigned long long z_n = 0, z_c = 0, o_n = 0, o_c = 0;
+#endif
         const unsigned long long t0_cyc = __builtin_amdgcn_s_memtime(), t0_real = __builtin_amdgcn_s_memrealtime();
         // the window it prepared (its closure records are written one phase later)
         long long idx = LL_MAX;
@@ -449,6 +482,10 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
             }
             CH_PHASE_END(active, W.k);
             st_b += __builtin_amdgcn_s_memtime() - ta0;
+#ifdef QS_CHAIN_PROF4
+            { const unsigned int qn = s_qcnt; const unsigned int dq = qn - q_prev; q_prev = qn;
+              if (dq == 0) { z_n++; z_c += __builtin_amdgcn_s_memtime() - ta0; } else if (dq == 1) { o_n++; o_c += __builtin_amdgcn_s_memtime() - ta0; } }
+#endif
         }
         if (lane == 0) {
             atomicAdd(&counters[QS_CNT_CLOSURES], (unsigned long long)(n_cls - n_cls0));
@@ -459,6 +496,10 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
             atomicAdd(&counters[QS_CNT_SLAM_CYCLES], __builtin_amdgcn_s_memtime() - t0_cyc);
             atomicAdd(&counters[QS_CNT_SLAM_REALTIME], __builtin_amdgcn_s_memrealtime() - t0_real);
             if (s_abort) atomicAdd(&counters[QS_CNT_SLAM_ABORT], 1ull);
+#ifdef QS_CHAIN_PROF4
+            atomicAdd(&counters[QS_CNT_SLAM_MISC_ITERS], z_n); atomicAdd(&counters[QS_CNT_SLAM_CYC_C], z_c);
+            atomicAdd(&counters[QS_CNT_SLAM_ROUNDS], o_n << 32); atomicAdd(&counters[QS_CNT_SLAM_NODE_ITERS], o_c << 20);
+#endif
             Gp->n_nodes = Gp->n_nodes + sb.acc_total[g];
             Gp->n_cls = n_cls;
         }
@@ -550,6 +591,9 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
                 long long best = LL_MAX, gbest = LL_MAX;
                 double bx = 0, by = 0;
                 st_rounds++;
+#ifdef QS_CHAIN_PROF4
+                if (lane == 0) atomicAdd(&s_qcnt, 1u);
+#endif
 #ifdef QS_CHAIN_PROF
                 const unsigned long long tq1 = __builtin_amdgcn_s_memtime();
 #endif
@@ -578,13 +622,11 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
                         nm = s_nmisc;
                         bool cand = false;
                         long long li = LL_MAX; double lx = 0, ly = 0;
-                        if (lane < 32) {
-                            li = i_idx[par ^ 1][lane];
-                            if (li <= limit && i_type[par ^ 1][lane] == qtype) {
-                                lx = i_x[par ^ 1][lane]; ly = i_y[par ^ 1][lane];
-                                const double dx = qx - lx, dy = qy - ly;
-                                cand = dx * dx + dy * dy < r2thr;
-                            }
+                        if (lane < 32) {                                   // (all four reads in one LDS round trip)
+                            li = i_idx[par ^ 1][lane]; lx = i_x[par ^ 1][lane]; ly = i_y[par ^ 1][lane];
+                            const int lt = i_type[par ^ 1][lane];
+                            const double dx = qx - lx, dy = qy - ly;
+                            cand = li <= limit && lt == qtype && dx * dx + dy * dy < r2thr;
                         }
                         const unsigned long long cm = __ballot(cand);
                         if (cm) {
@@ -606,13 +648,9 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
                         const double dx = qx - nx, dy = qy - ny;
                         if (dx * dx + dy * dy < r2thr) { best = id; bx = nx; by = ny; newhit = true; }   // :308-309
                     }
-                    // a node's entries are in node order, so the first lane of a bucket's group that hits holds the
-                    // group's lowest index: at most 9 candidates, however many landmarks are within the radius
-                    for (unsigned long long hm = __ballot(newhit); hm;) {
-                        const int hl = __ffsll((long long)hm) - 1;
-                        const long long v = rl64(best, hl);
+                    if (__ballot(newhit)) {
+                        const long long v = wave_min_nonneg_i64(newhit ? best : LL_MAX);   // node indices are >= 0
                         gbest = v < gbest ? v : gbest;
-                        hm &= ~(0x7full << ((hl / QS_NODE_CAP) * QS_NODE_CAP));
                     }
                     const unsigned long long hitm = __ballot(best != LL_MAX);
                     const unsigned long long limm = __ballot(inlim);
