@@ -147,6 +147,8 @@ def main():
                          seq_stride=world)
     stream_t = torch.cuda.current_stream()
     m.set_stream(stream_t.cuda_stream)
+    if args.bots != 2:
+        m.set_bot_offset(2, 0.0)     # the multi-bot stream places every bot in its own tile itself (no BOT_SEPARATION shift)
 
     def step(k):
         m.reset()

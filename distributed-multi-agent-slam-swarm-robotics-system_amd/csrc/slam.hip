@@ -148,11 +148,12 @@ qs_slam_index_kernel(size_t n, QsBatch b, QsSlamBatch sb, const QsGraphDev *__re
 }
 
 // ---- the chain: one workgroup (CH_WAVES waves) per pose graph ------------------------------------
-// Per window: wave 0 loads the window's events and prepares them SIMD-across-events (pose with the
-// drift at window start, eligibility, bucket key and 3x3 neighbour mask); the eligible events are
-// then queried, one wave per agent (its events in order, until the first match); wave 0 commits closures in node order and appends the
-// window's landmarks to the log and the spatial index.  A lone wave issues roughly one instruction
-// per 4-8 cycles, so everything that can be done once per window instead of once per query is.
+// The graph's landmark events are walked in windows of < MIN_POSES_BETWEEN nodes: a query never sees a
+// landmark of its own window (:300), and an agent closes at most once per window (:304), so the
+// queries of one window are independent of each other.  One role per wave, one barrier per window: see
+// qs_slam_chain_kernel.  A lone wave issues roughly one instruction per 4-8 cycles and the whole batch is
+// ONE chain of closure decisions (each shapes the landmarks the next may match), so what counts is the
+// number of instructions and LDS / memory round trips between one decision and the next.
 #define CH_WAVES 16
 #define CH_THREADS (CH_WAVES * QS_WAVE)
 #define CH_INS (CH_WAVES - 2)       // the wave that moves a committed window into the HBM index
@@ -173,7 +174,8 @@ __device__ inline void lds_barrier()
 __device__ inline int bucket_coord(double v, double b0, double inv_cell)
 {
     const double f = floor((v - b0) * inv_cell);
-    return (fabs(f) < 1.0e9) ? (int)f : -1000000000;     // one conversion instruction (f64 -> i64 is a sequence)
+    // one conversion instruction (f64 -> i64 is a sequence); monotone, so that clamping to the grid is too
+    return (fabs(f) < 1.0e9) ? (int)f : (f > 0 ? 1000000000 : -1000000000);
 }
 
 __device__ inline long long rl64(long long v, int src_lane)      // wave-uniform read of one lane
@@ -184,40 +186,35 @@ __device__ inline long long rl64(long long v, int src_lane)      // wave-uniform
     return ((long long)hi << 32) | (unsigned int)lo;
 }
 
-// bucket key of the 3x3 centre and the mask of neighbours that exist in the directory
+// bucket key of the 3x3 centre and the mask of neighbours that exist in the directory.  Points outside
+// the bucket grid go to its border buckets: clamping never moves two coordinates further apart, so two
+// points closer than the radius are still at most one bucket apart (only landmark types the directory
+// has no slab for end up in the side list).
 __device__ inline void bucket_prepare(double x, double y, int type, const QsBucketGeom &bg, long long dir_slab,
                                       long long &kb, unsigned int &nbmask)
 {
     kb = -1; nbmask = 0;
     if (type < 1 || type > QS_NTYPES) return;
-    const int cx = bucket_coord(x, bg.bx0, bg.inv_cell), cy = bucket_coord(y, bg.by0, bg.inv_cell);
-    if (cx < -1 || cx > bg.nbx || cy < -1 || cy > bg.nby) return;
+    const int cx = min(max(bucket_coord(x, bg.bx0, bg.inv_cell), 0), bg.nbx - 1);
+    const int cy = min(max(bucket_coord(y, bg.by0, bg.inv_cell), 0), bg.nby - 1);
     kb = (type - 1) * dir_slab + (long long)(cy * bg.nbx + cx);        // |cy * nbx + cx| < 2^23: buckets per axis <= 2048
     // bit q = 3 * (dy + 1) + (dx + 1) is set when neighbour (cx + dx, cy + dy) exists
-    const unsigned int xm = (cx >= 1 ? 1u : 0u) | ((cx >= 0 && cx < bg.nbx) ? 2u : 0u) | (cx + 1 < bg.nbx ? 4u : 0u);
-    nbmask = (cy >= 1 ? xm : 0u) | ((cy >= 0 && cy < bg.nby) ? xm << 3 : 0u) | (cy + 1 < bg.nby ? xm << 6 : 0u);
+    const unsigned int xm = (cx >= 1 ? 1u : 0u) | 2u | (cx + 1 < bg.nbx ? 4u : 0u);
+    nbmask = (cy >= 1 ? xm : 0u) | (xm << 3) | (cy + 1 < bg.nby ? xm << 6 : 0u);
 }
 
 
-// Landmark log and bucket index of the window committed last (LDS arrays i_*): run by wave CH_INS while
-// the next window's queries are in flight.  Those queries read the index for everything older and the
-// LDS arrays for this window, so nothing waits for these stores; they are complete (vmcnt) before the
-// barrier that ends the query phase, i.e. before the window after next looks for them in HBM.
-__device__ inline void chain_insert_window(const QsGraphDev &G, const long long *i_idx, const long long *i_kb, const double *i_x,
-                                           const double *i_y, const int *i_type, int k, int lane, long long &n_lms,
-                                           long long &n_misc, unsigned int &pool)
+// Landmark log and bucket index: `k` events of one graph, in node order, one per lane (`inw` lanes, rank =
+// the lane's position among them).  Appends to the reference's insertion-ordered log and to the bucket
+// chains; events of one bucket are appended in lane (= node) order.
+__device__ inline void chain_insert_lanes(const QsGraphDev &G, bool inw, int rank, long long idx, long long kb, double x, double y,
+                                          int type, int k, int lane, long long &n_lms, long long &n_misc, unsigned int &pool)
 {
-    const bool inw = lane < k;
-    const long long idx = lane < 32 ? i_idx[lane] : LL_MAX;
-    const long long kb = lane < 32 ? i_kb[lane] : -1;
-    const double x = lane < 32 ? i_x[lane] : 0, y = lane < 32 ? i_y[lane] : 0;
-    const int type = lane < 32 ? i_type[lane] : 0;
     // self.landmarks.append((x, y, landmark_type, idx))  :288
-    const long long log_slot = n_lms + lane;
+    const long long log_slot = n_lms + rank;
     if (inw && log_slot < G.cap_lms) {
         G.lm_x[log_slot] = x; G.lm_y[log_slot] = y; G.lm_idx[log_slot] = idx; G.lm_type[log_slot] = (unsigned char)type;
     }
-    // spatial index insert: events of one bucket are appended in lane (= node) order
     const bool inb = inw && kb >= 0;                              // the centre bucket exists
     const long long key = inb ? kb : -1;
     const bool is_misc = inw && !inb;
@@ -260,6 +257,21 @@ __device__ inline void chain_insert_window(const QsGraphDev &G, const long long 
         rem &= ~grp;
     }
     n_lms += k;
+}
+
+// the window committed last (LDS arrays i_*): run by wave CH_INS while the next window's queries are in
+// flight.  Those queries read the index for everything older and the LDS arrays for this window, so
+// nothing waits for these stores; they are complete (vmcnt) before the barrier that ends the phase,
+// i.e. before the window after next looks for them in HBM.
+__device__ inline void chain_insert_window(const QsGraphDev &G, const long long *i_idx, const long long *i_kb, const double *i_x,
+                                           const double *i_y, const int *i_type, int k, int lane, long long &n_lms,
+                                           long long &n_misc, unsigned int &pool)
+{
+    const long long idx = lane < 32 ? i_idx[lane] : LL_MAX;
+    const long long kb = lane < 32 ? i_kb[lane] : -1;
+    const double x = lane < 32 ? i_x[lane] : 0, y = lane < 32 ? i_y[lane] : 0;
+    const int type = lane < 32 ? i_type[lane] : 0;
+    chain_insert_lanes(G, lane < k, lane, idx, kb, x, y, type, k, lane, n_lms, n_misc, pool);
 }
 
 // The graph's pointers come out of a struct in memory, so the compiler has to treat them as FLAT
@@ -377,9 +389,6 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
     __shared__ long long s_nmisc;
     __shared__ int s_prepared;                  // windows laid out by wave 0 so far
     __shared__ int s_abort;
-#ifdef QS_CHAIN_PROF4
-    __shared__ unsigned int s_qcnt;
-#endif
 
     for (int t = tid; t < nb; t += CH_THREADS) {
         s_dx[0][t] = drift[2 * (bot0 + t)];
@@ -387,9 +396,6 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
         s_lastc[0][t] = last_closure[bot0 + t];
         s_acnt[t] = sb.agent_ev[bot0 + t];             // where the agent's next closure record goes
     }
-#ifdef QS_CHAIN_PROF4
-    if (tid == 0) s_qcnt = 0;
-#endif
     if (tid == 0) { s_nmisc = Gp->n_misc; s_ik[0] = 0; s_ik[1] = 0; s_prepared = 0; s_abort = 0; }
     if (tid < 64) {
         const int h = tid >> 5, t = tid & 31;
@@ -420,9 +426,6 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
         long long *const cl_lm_idx = Gp->cl_lm_idx, *const cl_node_idx = Gp->cl_node_idx;
         double *const cl_dx = Gp->cl_dx, *const cl_dy = Gp->cl_dy;
         unsigned long long st_windows = 0, st_a = 0, st_b = 0;
-#ifdef QS_CHAIN_PROF4
-        unsigned int q_prev = 0; unsigned long long z_n = 0, z_c = 0, o_n = 0, o_c = 0;
-#endif
         const unsigned long long t0_cyc = __builtin_amdgcn_s_memtime(), t0_real = __builtin_amdgcn_s_memrealtime();
         // the window it prepared (its closure records are written one phase later)
         long long idx = LL_MAX;
@@ -482,10 +485,6 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
             }
             CH_PHASE_END(active, W.k);
             st_b += __builtin_amdgcn_s_memtime() - ta0;
-#ifdef QS_CHAIN_PROF4
-            { const unsigned int qn = s_qcnt; const unsigned int dq = qn - q_prev; q_prev = qn;
-              if (dq == 0) { z_n++; z_c += __builtin_amdgcn_s_memtime() - ta0; } else if (dq == 1) { o_n++; o_c += __builtin_amdgcn_s_memtime() - ta0; } }
-#endif
         }
         if (lane == 0) {
             atomicAdd(&counters[QS_CNT_CLOSURES], (unsigned long long)(n_cls - n_cls0));
@@ -496,10 +495,6 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
             atomicAdd(&counters[QS_CNT_SLAM_CYCLES], __builtin_amdgcn_s_memtime() - t0_cyc);
             atomicAdd(&counters[QS_CNT_SLAM_REALTIME], __builtin_amdgcn_s_memrealtime() - t0_real);
             if (s_abort) atomicAdd(&counters[QS_CNT_SLAM_ABORT], 1ull);
-#ifdef QS_CHAIN_PROF4
-            atomicAdd(&counters[QS_CNT_SLAM_MISC_ITERS], z_n); atomicAdd(&counters[QS_CNT_SLAM_CYC_C], z_c);
-            atomicAdd(&counters[QS_CNT_SLAM_ROUNDS], o_n << 32); atomicAdd(&counters[QS_CNT_SLAM_NODE_ITERS], o_c << 20);
-#endif
             Gp->n_nodes = Gp->n_nodes + sb.acc_total[g];
             Gp->n_cls = n_cls;
         }
@@ -591,9 +586,6 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
                 long long best = LL_MAX, gbest = LL_MAX;
                 double bx = 0, by = 0;
                 st_rounds++;
-#ifdef QS_CHAIN_PROF4
-                if (lane == 0) atomicAdd(&s_qcnt, 1u);
-#endif
 #ifdef QS_CHAIN_PROF
                 const unsigned long long tq1 = __builtin_amdgcn_s_memtime();
 #endif

@@ -602,6 +602,15 @@ def test_api_edge_cases_and_errors(pkg):
             o.feed(d)
         assert len(o.closures(0)[0]) > 0 and (m.closures(0)[0] == o.closures(0)[0]).all()
         assert m.counters()["slam_misc_iters"] > 0 and (m.grid_i8() == -1).all()
+    # an indexed type far outside the bucket grid: the border buckets take it, no side list
+    pk = [P.pack_packet(1 + (i & 1), -80.0 + 0.01 * (i % 3), 60.0, 0.0, i, 0, 0.0, 0.0, 0.0, 0.0, 5 if i % 10 < 2 else 0) for i in range(6000)]
+    with pkg.QuasarMapper() as m:
+        m.ingest(pk)
+        o = orc.OracleMapper()
+        for d in pk:
+            o.feed(d)
+        assert len(o.closures(0)[0]) > 0 and (m.closures(0)[0] == o.closures(0)[0]).all() and (m.closures(0)[1] == o.closures(0)[1]).all()
+        assert m.counters()["slam_misc_iters"] == 0
 
 
 def _rigid(theta, tx, ty):
