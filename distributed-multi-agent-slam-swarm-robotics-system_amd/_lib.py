@@ -14,7 +14,7 @@ HEADER = os.path.join(os.path.dirname(_HERE), "include", "quasar_slam.h")
 
 QS_CNT_NAMES = ("datagrams", "accepted", "rays", "cells", "hits", "closures", "landmarks", "rebases",
                 "slam_windows", "slam_rounds", "slam_node_iters", "slam_misc_iters", "slam_cycles",
-                "slam_realtime_100mhz", "slam_cyc_prepare", "slam_cyc_query", "slam_cyc_commit", "ekf_wrap_clamp", "slam_abort")
+                "slam_realtime_100mhz", "slam_cyc_prepare", "slam_cyc_query", "slam_cyc_commit", "ekf_wrap_clamp")
 QS_STAGE_NAMES = ("decode", "slam", "raycast", "ekf")
 UINT64_MAX = (1 << 64) - 1
 

@@ -263,14 +263,15 @@ __device__ inline void chain_insert_lanes(const QsGraphDev &G, bool inw, int ran
 // flight.  Those queries read the index for everything older and the LDS arrays for this window, so
 // nothing waits for these stores; they are complete (vmcnt) before the barrier that ends the phase,
 // i.e. before the window after next looks for them in HBM.
-__device__ inline void chain_insert_window(const QsGraphDev &G, const long long *i_idx, const long long *i_kb, const double *i_x,
-                                           const double *i_y, const int *i_type, int k, int lane, long long &n_lms,
-                                           long long &n_misc, unsigned int &pool)
+__device__ inline void chain_insert_window(const QsGraphDev &G, const QsBucketGeom &bg, long long dir_slab, const long long *i_idx,
+                                           const double *i_x, const double *i_y, const int *i_type, int k, int lane,
+                                           long long &n_lms, long long &n_misc, unsigned int &pool)
 {
     const long long idx = lane < 32 ? i_idx[lane] : LL_MAX;
-    const long long kb = lane < 32 ? i_kb[lane] : -1;
     const double x = lane < 32 ? i_x[lane] : 0, y = lane < 32 ? i_y[lane] : 0;
-    const int type = lane < 32 ? i_type[lane] : 0;
+    const int type = lane < k ? i_type[lane] : 0;
+    long long kb; unsigned int nbm;
+    bucket_prepare(x, y, type, bg, dir_slab, kb, nbm);          // kb < 0: a type without a slab (side list)
     chain_insert_lanes(G, lane < k, lane, idx, kb, x, y, type, k, lane, n_lms, n_misc, pool);
 }
 
@@ -309,33 +310,19 @@ __device__ inline long long wave_min_nonneg_i64(long long v)
     return (long long)(((unsigned long long)mhi << 32) | mlo);
 }
 
-// wait until the commits counter (LDS) reaches `want`.  The writer (wave 0) sets it unconditionally, in
-// program order, before it reaches the phase's barrier, and no waiter holds anything wave 0 needs: the
-// wait cannot cycle.  The bound only turns a logic error into a counted abort instead of a hung GPU.
-// (a relaxed atomic load, not a volatile one: the compiler keeps a volatile access through a pointer
-// as a FLAT load, whose wait also waits for every outstanding global load of the wave)
-__device__ inline bool chain_wait_commit(const int *commits, int want)
-{
-    for (int spin = 0; spin < (1 << 22); spin++) {
-        if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(commits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) >= want) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-            return true;
-        }
-        __builtin_amdgcn_s_sleep(1);
-    }
-    return false;
-}
-
 // the window at the head of the events: the next events whose node index is < first + win (a
 // contiguous prefix of the lanes).  Every role computes it for itself from the same LDS arrays.
-struct ChWindow { long long v_idx, first; int v_a, k; bool have, v_inw; };
+struct ChWindow { long long v_idx, first; double px, py; int v_a, type, k; bool have, v_inw; };
 __device__ inline ChWindow chain_window(const long long *nidx, const int *na, bool active, unsigned int e, unsigned int e1,
-                                        int lane, int win)
+                                        int lane, int win, const int *ntype = nullptr, const double *npx = nullptr,
+                                        const double *npy = nullptr)
 {
     ChWindow w;
     w.have = active && lane < 32 && e + lane < e1;
     w.v_idx = w.have ? nidx[lane] : LL_MAX;
     w.v_a = w.have ? na[lane] : 0;
+    w.type = (ntype && w.have) ? ntype[lane] : 0;                 // (one LDS round trip for all the lane's event data)
+    w.px = (npx && w.have) ? npx[lane] : 0; w.py = (npy && w.have) ? npy[lane] : 0;
     w.first = rl64(w.v_idx, 0);
     w.v_inw = w.have && w.v_idx - w.first < win;
     w.k = __popcll(__ballot(w.v_inw));
@@ -345,18 +332,19 @@ __device__ inline ChWindow chain_window(const long long *nidx, const int *na, bo
 // One workgroup per pose graph, one role per wave, one phase per window, one barrier per phase.  Each role
 // runs its OWN loop over the phases (the same count in every role: it follows from the events alone), so
 // that a role's loop keeps only that role's pointers and constants in registers.  In phase V, side by side:
-//   wave 0          writes the closure records of window V - 1 in node order, then poses ALL of window V's
-//                   events with the drift at window start and lays them out as the window's landmarks (LDS)
+//   wave 0          writes the closure records of window V - 1 in node order (each closing event's pose under
+//                   the drift at window start is its own arithmetic), then lays out window V's landmarks:
+//                   node index and type (LDS)
 //   waves 1..CH_AGW each agent's owner finds the agent's first eligible event of window V, poses it, and
 //                   scans the index for it -- the index holds everything up to window V - 2, window V - 1's
 //                   landmarks (final poses) are in LDS; then the agent's next event, until a match: only an
 //                   agent's FIRST eligible event with a match closes the loop (:304-318).  The owner applies
-//                   the closure itself (the arithmetic is wave 0's, on the same operands): to its agent's
-//                   state, and to the poses of the agent's later events in the window's landmarks
+//                   the closure itself (the arithmetic is wave 0's, on the same operands) to its agent's
+//                   state, and gives the agent's events in the window their final pose (LDS)
 //   wave CH_INS     moves window V - 1's landmarks into the index
 //   the last wave   fetches the events after window V.
-// Nothing inside a phase waits for another wave, except an owner that patches poses (it needs wave 0's
-// layout of the window: a flag it almost always finds set).
+// Nothing inside a phase waits for another wave: every LDS word has one writer per phase and its readers
+// come a barrier later.
 // Waves without a role leave at once (a barrier counts the waves still running).
 __global__ void __launch_bounds__(CH_THREADS)
 qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGeom bg, int bots_per_graph,
@@ -382,13 +370,11 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
     __shared__ long long n_idx[2][32];          // events of the current window / the one after it (by parity)
     __shared__ double n_px[2][32], n_py[2][32];
     __shared__ int n_a[2][32], n_type[2][32];
-    __shared__ long long i_idx[2][32], i_kb[2][32];   // a window's landmarks (by window parity): node index, bucket,
-    __shared__ double i_x[2][32], i_y[2][32];         // pose.  Final at the end of the window's phase; read by the next
+    __shared__ long long i_idx[2][32];                // a window's landmarks (by window parity): node index, type (wave 0),
+    __shared__ double i_x[2][32], i_y[2][32];         // pose (each agent's owner).  Final at the end of the window's phase; read by the next
     __shared__ int i_type[2][32];                     // window's queries and moved into the index by wave CH_INS
     __shared__ int s_ik[2];
     __shared__ long long s_nmisc;
-    __shared__ int s_prepared;                  // windows laid out by wave 0 so far
-    __shared__ int s_abort;
 
     for (int t = tid; t < nb; t += CH_THREADS) {
         s_dx[0][t] = drift[2 * (bot0 + t)];
@@ -396,10 +382,10 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
         s_lastc[0][t] = last_closure[bot0 + t];
         s_acnt[t] = sb.agent_ev[bot0 + t];             // where the agent's next closure record goes
     }
-    if (tid == 0) { s_nmisc = Gp->n_misc; s_ik[0] = 0; s_ik[1] = 0; s_prepared = 0; s_abort = 0; }
+    if (tid == 0) { s_nmisc = Gp->n_misc; s_ik[0] = 0; s_ik[1] = 0; }
     if (tid < 64) {
         const int h = tid >> 5, t = tid & 31;
-        i_idx[h][t] = LL_MAX; i_kb[h][t] = -1; i_x[h][t] = 0; i_y[h][t] = 0; i_type[h][t] = 0; w_ridx[h][t] = LL_MAX;
+        i_idx[h][t] = LL_MAX; i_x[h][t] = 0; i_y[h][t] = 0; i_type[h][t] = 0; w_ridx[h][t] = LL_MAX;
     }
 
     const unsigned int e0 = sb.ev_base[g], e1 = sb.ev_base[g + 1];
@@ -414,10 +400,10 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
     __syncthreads();
 
     unsigned int e = e0;
-    int par = 0, phase = 0;
+    int par = 0;
     bool have_prev = false;
-// what every role does at the end of a phase (s_abort is read after the barrier: uniform)
-#define CH_PHASE_END(active_, k_)  lds_barrier(); e += (k_); have_prev = (active_); if (active_) par ^= 1; if (s_abort) break
+// what every role does at the end of a phase
+#define CH_PHASE_END(active_, k_)  lds_barrier(); e += (k_); have_prev = (active_); if (active_) par ^= 1
 
     if (wave == 0) {
         // =================================== wave 0: commit + prepare ===================================
@@ -432,11 +418,11 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
         int a = 0;
         double x = 0, y = 0;
         bool inw = false;
-        for (;; phase++) {
+        for (;;) {
             const bool active = e < e1;
             if (!active && !have_prev) break;
             const unsigned long long ta0 = __builtin_amdgcn_s_memtime();
-            const ChWindow W = chain_window(n_idx[par], n_a[par], active, e, e1, lane, win);
+            const ChWindow W = chain_window(n_idx[par], n_a[par], active, e, e1, lane, win, n_type[par], n_px[par], n_py[par]);
             if (have_prev) {
                 // ---- closure records of window V - 1, in node order ----
                 const long long m_idx = lane < 32 ? w_ridx[par ^ 1][lane] : LL_MAX;
@@ -461,24 +447,15 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
                 st_a += __builtin_amdgcn_s_memtime() - ta0;
             }
             if (active) {
-                // ---- window V: pose with the drift at window start, bucket key + 3x3 neighbour mask; laid out
-                // as the window's landmarks: self.landmarks.append(...)  :288 ----
-                long long kb; unsigned int nbm;
-                int type = 0; double px = 0, py = 0;
+                // ---- window V: the events' poses with the drift at window start (what a closing event is matched
+                // at); node index and type laid out as the window's landmarks: self.landmarks.append(...)  :288 ----
                 idx = W.v_idx; a = W.v_a;
-                if (W.have) { type = n_type[par][lane]; px = n_px[par][lane]; py = n_py[par][lane]; }
                 inw = W.v_inw;
-                if (!inw) { a = 0; type = 0; }
-                x = raw_pose ? px : px + s_dx[par][a];                  // rx += cdx  :856
-                y = raw_pose ? py : py + s_dy[par][a];                  // ry += cdy  :857
-                bucket_prepare(x, y, type, bg, dir_slab, kb, nbm);
-                if (lane < 32) {
-                    i_idx[par][lane] = inw ? idx : LL_MAX; i_x[par][lane] = x; i_y[par][lane] = y; i_type[par][lane] = type;
-                    i_kb[par][lane] = (inw && kb >= 0 && ((nbm >> 4) & 1u)) ? kb : -1;      // -1: not in the directory (side list)
-                }
+                if (!inw) a = 0;
+                x = raw_pose ? W.px : W.px + s_dx[par][a];              // rx += cdx  :856
+                y = raw_pose ? W.py : W.py + s_dy[par][a];              // ry += cdy  :857
+                if (lane < 32) { i_idx[par][lane] = inw ? idx : LL_MAX; i_type[par][lane] = inw ? W.type : 0; }
                 if (lane == 0) s_ik[par] = W.k;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-                if (lane == 0) __hip_atomic_store(&s_prepared, phase + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 st_windows++;
             } else {
                 inw = false;
@@ -494,14 +471,13 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
 #endif
             atomicAdd(&counters[QS_CNT_SLAM_CYCLES], __builtin_amdgcn_s_memtime() - t0_cyc);
             atomicAdd(&counters[QS_CNT_SLAM_REALTIME], __builtin_amdgcn_s_memrealtime() - t0_real);
-            if (s_abort) atomicAdd(&counters[QS_CNT_SLAM_ABORT], 1ull);
             Gp->n_nodes = Gp->n_nodes + sb.acc_total[g];
             Gp->n_cls = n_cls;
         }
         for (int t = lane; t < nb; t += QS_WAVE) sb.acl_cnt[bot0 + t] = s_acnt[t] - sb.agent_ev[bot0 + t];
     } else if (wave == CH_WAVES - 1) {
         // =================================== the last wave: event fetch ===================================
-        for (;; phase++) {
+        for (;;) {
             const bool active = e < e1;
             if (!active && !have_prev) break;
             const ChWindow W = chain_window(n_idx[par], n_a[par], active, e, e1, lane, win);
@@ -519,13 +495,13 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
         const QsGraphDev G = *Gp;
         long long n_lms = G.n_lms, n_misc = G.n_misc;
         unsigned int pool = G.nodes_used;
-        for (;; phase++) {
+        for (;;) {
             const bool active = e < e1;
             if (!active && !have_prev) break;
             const ChWindow W = chain_window(n_idx[par], n_a[par], active, e, e1, lane, win);
             if (have_prev) {
                 if (s_ik[par ^ 1] > 0) {
-                    chain_insert_window(G, i_idx[par ^ 1], i_kb[par ^ 1], i_x[par ^ 1], i_y[par ^ 1], i_type[par ^ 1], s_ik[par ^ 1], lane,
+                    chain_insert_window(G, bg, dir_slab, i_idx[par ^ 1], i_x[par ^ 1], i_y[par ^ 1], i_type[par ^ 1], s_ik[par ^ 1], lane,
                                         n_lms, n_misc, pool);
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the stores are done before the phase ends ...
                     if (lane == 0) s_nmisc = n_misc;                         // ... and before the side list's new length shows
@@ -559,10 +535,10 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
 #if defined(QS_CHAIN_PROF) || defined(QS_CHAIN_PROF3)
         unsigned long long pq_a = 0, pq_b = 0, pq_c = 0, pq_d = 0;
 #endif
-        for (;; phase++) {
+        for (;;) {
             const bool active = e < e1;
             if (!active && !have_prev) break;
-            const ChWindow W = chain_window(n_idx[par], n_a[par], active, e, e1, lane, win);
+            const ChWindow W = chain_window(n_idx[par], n_a[par], active, e, e1, lane, win, n_type[par], n_px[par], n_py[par]);
             unsigned int done = 0;                      // bit a / CH_AGW: agent a has its match
             for (unsigned long long qrem = __ballot(W.v_inw && (W.v_a % CH_AGW) + 1 == wave); qrem; qrem &= qrem - 1) {
 #ifdef QS_CHAIN_PROF
@@ -575,9 +551,10 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
                 const long long qidx = rl64(W.v_idx, src);
                 if (qidx - rl64(c_last, ql) < min_between) continue;                // :304
                 const double odx = rlf64(c_dx, ql), ody = rlf64(c_dy, ql);
-                const double qx = raw_pose ? n_px[par][src] : n_px[par][src] + odx;   // rx += cdx  :856
-                const double qy = raw_pose ? n_py[par][src] : n_py[par][src] + ody;   // ry += cdy  :857
-                const int qtype = n_type[par][src];
+                const double spx = rlf64(W.px, src), spy = rlf64(W.py, src);
+                const double qx = raw_pose ? spx : spx + odx;                         // rx += cdx  :856
+                const double qy = raw_pose ? spy : spy + ody;                         // ry += cdy  :857
+                const int qtype = __builtin_amdgcn_readlane(W.type, src);
                 const long long limit = qidx - min_between;                        // :300
                 long long qkb; unsigned int qnbm;
                 bucket_prepare(qx, qy, qtype, bg, dir_slab, qkb, qnbm);
@@ -703,24 +680,21 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
                     const double cdx = ex * corr, cdy = ey * corr;                             // :314-315
                     const double ndx = odx + cdx, ndy = ody + cdy;                             // :911-914
                     if (lane == ql) { c_dx = ndx; c_dy = ndy; c_last = qidx; }                 // :318
-                    // later events of the agent in this window are posed (and stored) with the new drift
-                    const bool later = !raw_pose && W.v_inw && W.v_a == qa && W.v_idx > qidx;
-                    if (__ballot(later)) {
-                        if (!chain_wait_commit(&s_prepared, phase + 1)) s_abort = 1;          // wave 0's layout first
-                        if (later) {
-                            const double lx = n_px[par][lane] + ndx, ly = n_py[par][lane] + ndy;
-                            long long lkb; unsigned int lnbm;
-                            bucket_prepare(lx, ly, n_type[par][lane], bg, dir_slab, lkb, lnbm);
-                            i_x[par][lane] = lx; i_y[par][lane] = ly;
-                            i_kb[par][lane] = (lkb >= 0 && ((lnbm >> 4) & 1u)) ? lkb : -1;
-                        }
-                    }
                 }
 #ifdef QS_CHAIN_PROF
                 { const unsigned long long tq3 = __builtin_amdgcn_s_memtime(); pq_a += tq1 - tq0; pq_b += tq2 - tq1; pq_c += tq3 - tq2; }
 #endif
             }
             if (active && own < nb) { s_dx[par ^ 1][own] = c_dx; s_dy[par ^ 1][own] = c_dy; s_lastc[par ^ 1][own] = c_last; }
+            // the window's landmarks get their final pose from their agent's owner: the drift at window start,
+            // or -- later events of an agent that closed in this window -- the drift after the closure (:855-857)
+            if (W.v_inw && (W.v_a % CH_AGW) + 1 == wave) {
+                const int va = W.v_a;
+                const bool after = W.v_idx > s_lastc[par ^ 1][va];        // (own rows of the state, written just above)
+                const double ddx = after ? s_dx[par ^ 1][va] : s_dx[par][va], ddy = after ? s_dy[par ^ 1][va] : s_dy[par][va];
+                i_x[par][lane] = raw_pose ? W.px : W.px + ddx;
+                i_y[par][lane] = raw_pose ? W.py : W.py + ddy;
+            }
             CH_PHASE_END(active, W.k);
         }
         if (own < nb) {

@@ -186,12 +186,10 @@ int qs_ekf_step(qs_ctx *ctx, const int32_t *bot_ids, const double *omega_m, cons
 int qs_ekf_state(qs_ctx *ctx, int32_t bot, double x[6], double P[36]);
 
 /* ---- counters / timing ------------------------------------------------------------------ */
-/* QS_CNT_SLAM_ABORT: loop-closure chains that gave up on an internal hand-off (always 0; non-zero means
- * the closure results of that ingest are not to be trusted -- a defect, please report). */
 enum { QS_CNT_DATAGRAMS = 0, QS_CNT_ACCEPTED, QS_CNT_RAYS, QS_CNT_CELLS, QS_CNT_HITS,
        QS_CNT_CLOSURES, QS_CNT_LANDMARKS, QS_CNT_REBASES, QS_CNT_SLAM_WINDOWS, QS_CNT_SLAM_ROUNDS,
        QS_CNT_SLAM_NODE_ITERS, QS_CNT_SLAM_MISC_ITERS, QS_CNT_SLAM_CYCLES, QS_CNT_SLAM_REALTIME, QS_CNT_SLAM_CYC_A, QS_CNT_SLAM_CYC_B,
-       QS_CNT_SLAM_CYC_C, QS_CNT_EKF_WRAP_CLAMP, QS_CNT_SLAM_ABORT, QS_CNT_N };
+       QS_CNT_SLAM_CYC_C, QS_CNT_EKF_WRAP_CLAMP, QS_CNT_N };
 int qs_counters(qs_ctx *ctx, uint64_t out[QS_CNT_N]);
 /* HIP-event timing of the pipeline stages on the context's stream.  enable != 0 brackets
  * each stage of every ingest with events; qs_stage_times returns accumulated ms and the
