@@ -466,7 +466,7 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
         if (lane == 0) {
             atomicAdd(&counters[QS_CNT_CLOSURES], (unsigned long long)(n_cls - n_cls0));
             atomicAdd(&counters[QS_CNT_SLAM_WINDOWS], st_windows);
-#if !defined(QS_CHAIN_PROF) && !defined(QS_CHAIN_PROF3)
+#if !defined(QS_CHAIN_PROF) && !defined(QS_CHAIN_PROF3) && !defined(QS_CHAIN_PROF5)
             atomicAdd(&counters[QS_CNT_SLAM_CYC_A], st_a); atomicAdd(&counters[QS_CNT_SLAM_CYC_B], st_b);
 #endif
             atomicAdd(&counters[QS_CNT_SLAM_CYCLES], __builtin_amdgcn_s_memtime() - t0_cyc);
@@ -532,15 +532,21 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
         const int last_lane = min(nbk * QS_NODE_CAP + QS_NODE_CAP - 1, 63);
         const long long nb_off = ((nbk / 3) - 1) * (long long)bg.nbx + (nbk % 3) - 1;
         unsigned long long st_rounds = 0, st_iters = 0, st_misc = 0;
-#if defined(QS_CHAIN_PROF) || defined(QS_CHAIN_PROF3)
+#if defined(QS_CHAIN_PROF) || defined(QS_CHAIN_PROF3) || defined(QS_CHAIN_PROF5)
         unsigned long long pq_a = 0, pq_b = 0, pq_c = 0, pq_d = 0;
 #endif
         for (;;) {
             const bool active = e < e1;
             if (!active && !have_prev) break;
+#ifdef QS_CHAIN_PROF5
+            const unsigned long long v0 = __builtin_amdgcn_s_memtime();
+            unsigned long long v1 = 0, v2 = 0;
+#endif
             const ChWindow W = chain_window(n_idx[par], n_a[par], active, e, e1, lane, win, n_type[par], n_px[par], n_py[par]);
             unsigned int done = 0;                      // bit a / CH_AGW: agent a has its match
-            for (unsigned long long qrem = __ballot(W.v_inw && (W.v_a % CH_AGW) + 1 == wave); qrem; qrem &= qrem - 1) {
+            const double o_dx = rlf64(c_dx, 0), o_dy = rlf64(c_dy, 0);     // lane 0's agent: drift at window start
+            const bool ownlane = W.v_inw && (W.v_a % CH_AGW) + 1 == wave;
+            for (unsigned long long qrem = __ballot(ownlane); qrem; qrem &= qrem - 1) {
 #ifdef QS_CHAIN_PROF
                 const unsigned long long tq0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -550,6 +556,9 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
                 if ((done >> ql) & 1u) continue;
                 const long long qidx = rl64(W.v_idx, src);
                 if (qidx - rl64(c_last, ql) < min_between) continue;                // :304
+#ifdef QS_CHAIN_PROF5
+                if (!v1) v1 = __builtin_amdgcn_s_memtime();
+#endif
                 const double odx = rlf64(c_dx, ql), ody = rlf64(c_dy, ql);
                 const double spx = rlf64(W.px, src), spy = rlf64(W.py, src);
                 const double qx = raw_pose ? spx : spx + odx;                         // rx += cdx  :856
@@ -674,6 +683,8 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
                 if (l_idx < gbest) { gbest = l_idx; wx = l_x; wy = l_y; }
                 if (gbest != LL_MAX) {
                     done |= 1u << ql;
+                    // the agent's later events cannot close (:304): off the wave's list (this one goes with the loop step)
+                    qrem &= ~(__ballot(W.v_a == qa) & ~((2ull << src) - 1));
                     if (lane == 0) { w_ridx[par][src] = gbest; w_rx[par][src] = wx; w_ry[par][src] = wy; }
                     // the closure, applied to the agent's state by its owner (wave 0 writes the records)
                     const double ex = wx - qx, ey = wy - qy;                                   // :311-312
@@ -681,6 +692,9 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
                     const double ndx = odx + cdx, ndy = ody + cdy;                             // :911-914
                     if (lane == ql) { c_dx = ndx; c_dy = ndy; c_last = qidx; }                 // :318
                 }
+#ifdef QS_CHAIN_PROF5
+                v2 = __builtin_amdgcn_s_memtime();
+#endif
 #ifdef QS_CHAIN_PROF
                 { const unsigned long long tq3 = __builtin_amdgcn_s_memtime(); pq_a += tq1 - tq0; pq_b += tq2 - tq1; pq_c += tq3 - tq2; }
 #endif
@@ -688,14 +702,24 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
             if (active && own < nb) { s_dx[par ^ 1][own] = c_dx; s_dy[par ^ 1][own] = c_dy; s_lastc[par ^ 1][own] = c_last; }
             // the window's landmarks get their final pose from their agent's owner: the drift at window start,
             // or -- later events of an agent that closed in this window -- the drift after the closure (:855-857)
-            if (W.v_inw && (W.v_a % CH_AGW) + 1 == wave) {
+            if (nb <= CH_AGW) {                                           // one agent per owner: its state is in lane 0
+                const bool after = W.v_idx > rl64(c_last, 0);
+                const double ddx = after ? rlf64(c_dx, 0) : o_dx, ddy = after ? rlf64(c_dy, 0) : o_dy;
+                if (ownlane) { i_x[par][lane] = raw_pose ? W.px : W.px + ddx; i_y[par][lane] = raw_pose ? W.py : W.py + ddy; }
+            } else if (ownlane) {
                 const int va = W.v_a;
                 const bool after = W.v_idx > s_lastc[par ^ 1][va];        // (own rows of the state, written just above)
                 const double ddx = after ? s_dx[par ^ 1][va] : s_dx[par][va], ddy = after ? s_dy[par ^ 1][va] : s_dy[par][va];
                 i_x[par][lane] = raw_pose ? W.px : W.px + ddx;
                 i_y[par][lane] = raw_pose ? W.py : W.py + ddy;
             }
+#ifdef QS_CHAIN_PROF5
+            const unsigned long long v3 = __builtin_amdgcn_s_memtime();
             CH_PHASE_END(active, W.k);
+            if (v1 && v2) { pq_a += v1 - v0; pq_b += v2 - v1; pq_c += v3 - v2; pq_d += __builtin_amdgcn_s_memtime() - v3; }
+#else
+            CH_PHASE_END(active, W.k);
+#endif
         }
         if (own < nb) {
             drift[2 * (bot0 + own)] = c_dx;
@@ -706,7 +730,7 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
             atomicAdd(&counters[QS_CNT_SLAM_ROUNDS], st_rounds);
             atomicAdd(&counters[QS_CNT_SLAM_NODE_ITERS], st_iters);
             atomicAdd(&counters[QS_CNT_SLAM_MISC_ITERS], st_misc);
-#if defined(QS_CHAIN_PROF) || defined(QS_CHAIN_PROF3)
+#if defined(QS_CHAIN_PROF) || defined(QS_CHAIN_PROF3) || defined(QS_CHAIN_PROF5)
             atomicAdd(&counters[QS_CNT_SLAM_CYC_A], pq_a); atomicAdd(&counters[QS_CNT_SLAM_CYC_B], pq_b); atomicAdd(&counters[QS_CNT_SLAM_CYC_C], pq_c);
             atomicAdd(&counters[QS_CNT_SLAM_MISC_ITERS], pq_d);
 #endif
