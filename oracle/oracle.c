@@ -59,6 +59,8 @@ typedef struct {
     double *offset_x;                       /* per bot; bot 2 = --separation  :851-852 */
     double *drift;                          /* per bot (cdx, cdy)  :782 */
     long *last_closure;                     /* per bot, init -MIN_POSES_BETWEEN  :271 */
+    double closure_radius, closure_correction; long min_poses_between;   /* the reference's module constants (:99-101);
+                                               settable here because the product's qs_config exposes them */
     double *zone;                           /* per bot (minx,miny,maxx,maxy) over hits U path */
     long *zone_n;                           /* per bot number of points folded in */
     long *pkt_count;                        /* per bot  :848 */
@@ -119,14 +121,14 @@ static int check_closure(mapper_t *m, graph_t *g, long idx, int agent, int lm_ty
     for (long i = 0; i < g->n_lms; i++) {
         const landmark_t *l = &g->lms[i];
         if (l->type != lm_type) continue;                              /* :296 */
-        if (idx - l->idx < MIN_POSES_BETWEEN) continue;                 /* :300 */
-        if (idx - m->last_closure[agent] < MIN_POSES_BETWEEN) continue; /* :304 */
+        if (idx - l->idx < m->min_poses_between) continue;              /* :300 */
+        if (idx - m->last_closure[agent] < m->min_poses_between) continue; /* :304 */
         /* :308  math.sqrt((node.x - lm_x)**2 + (node.y - lm_y)**2); float**2 is libm pow */
         double dist = sqrt(pow(nx - l->x, 2.0) + pow(ny - l->y, 2.0));
-        if (dist < CLOSURE_RADIUS) {                                    /* :309 */
+        if (dist < m->closure_radius) {                                 /* :309 */
             double ex = l->x - nx, ey = l->y - ny;                      /* :311-312 */
-            *cdx = ex * CLOSURE_CORRECTION;                             /* :314-315 */
-            *cdy = ey * CLOSURE_CORRECTION;
+            *cdx = ex * m->closure_correction;                          /* :314-315 */
+            *cdy = ey * m->closure_correction;
             if (g->n_cls == g->cap_cls) {
                 g->cap_cls = g->cap_cls ? 2 * g->cap_cls : 64;
                 g->cls = realloc(g->cls, g->cap_cls * sizeof(closure_t));
@@ -180,8 +182,16 @@ mapper_t *qso_create(int size, double res, double ox, double oy, double separati
     m->zone = malloc(4 * nb * sizeof(double));
     m->zone_n = calloc(nb, sizeof(long));
     m->pkt_count = calloc(nb, sizeof(long));
+    m->closure_radius = CLOSURE_RADIUS; m->min_poses_between = MIN_POSES_BETWEEN; m->closure_correction = CLOSURE_CORRECTION;
     for (int b = 0; b < nb; b++) m->last_closure[b] = -MIN_POSES_BETWEEN;
     return m;
+}
+
+/* before the first packet: other values of the closure constants (last_closure restarts at -min_between, :271) */
+void qso_set_closure_params(mapper_t *m, double radius, long min_between, double correction)
+{
+    m->closure_radius = radius; m->min_poses_between = min_between; m->closure_correction = correction;
+    for (int b = 0; b <= m->max_agent; b++) m->last_closure[b] = -min_between;
 }
 
 void qso_destroy(mapper_t *m)

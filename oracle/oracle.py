@@ -35,6 +35,7 @@ def lib():
         L.qso_create.argtypes = [i32, f64, f64, f64, f64, i32, i32]
         L.qso_destroy.argtypes = [vp]
         L.qso_set_offset.argtypes = [vp, i32, f64]
+        L.qso_set_closure_params.argtypes = [vp, f64, i64, f64]
         L.qso_feed.restype = i32
         L.qso_feed.argtypes = [vp, vp, i32]
         L.qso_feed_stream.restype = i64
@@ -108,6 +109,10 @@ class OracleMapper:
 
     def set_offset(self, bot, off_x):
         lib().qso_set_offset(self._h, bot, off_x)
+
+    def set_closure_params(self, radius=0.6, min_between=30, correction=0.5):
+        """Other values of CLOSURE_RADIUS / MIN_POSES_BETWEEN / CLOSURE_CORRECTION (:99-101); before the first packet."""
+        lib().qso_set_closure_params(self._h, radius, min_between, correction)
 
     def feed(self, datagram: bytes) -> int:
         b = np.frombuffer(datagram, dtype=np.uint8) if len(datagram) else np.zeros(1, np.uint8)

@@ -16,6 +16,28 @@ from oracle import oracle as orc
 
 pytestmark = pytest.mark.gpu
 
+@pytest.mark.parametrize("radius,min_between,corr", [(0.6, 1, 0.5), (0.3, 5, 0.25), (1.0, 64, 0.5), (0.6, 0, 1.0), (0.45, 31, 0.1)])
+def test_closure_constants_other_than_the_reference(pkg, radius, min_between, corr):
+    """CLOSURE_RADIUS / MIN_POSES_BETWEEN / CLOSURE_CORRECTION (:99-101) are module constants in the reference and
+    fields of qs_config here: windows of 1 node, windows capped at 32 nodes below MIN_POSES_BETWEEN = 64, no
+    cool-down at all -- same closures, landmarks, drift and grid as the reference's loop with those constants."""
+    g = load("session_512")
+    stream = np.tile(g["datagrams"][:, :42], (12, 1))
+    o = orc.OracleMapper(512, 0.05, -12.8, -12.8, 0.0)
+    o.set_closure_params(radius, min_between, corr)
+    o.feed_stream(stream)
+    with pkg.QuasarMapper(512, 0.05, -12.8, -12.8, closure_radius=radius, min_poses_between=min_between,
+                          closure_correction=corr) as m:
+        m.ingest_array(stream[:5000]); m.ingest_array(stream[5000:])
+        idx, cc = m.closures(0); oi, oc = o.closures(0)
+        assert len(oi) > 50 and (idx == oi).all() and np.abs(cc - oc).max() < FLOAT_TOL
+        xy, ti = m.landmarks(0); oxy, oti = o.landmarks(0)
+        assert (ti == oti).all() and np.abs(xy - oxy).max() < FLOAT_TOL
+        for b in (1, 2):
+            assert np.abs(m.drift(b) - o.drift(b)).max() < FLOAT_TOL
+        assert (m.grid_i8() == o.grid).all()
+
+
 SCENARIOS = ["session_200", "session_512", "session_4096", "session_sep_512", "laps5_512",
              "session_fine_1024", "mixed_200", "adversarial_512", "adversarial_dense_200"]
 FLOAT_TOL = 1e-5
