@@ -200,14 +200,16 @@ extern "C" int qs_create(const qs_config *cfg, qs_ctx **out)
     c->cells = (size_t)cfg->size * cfg->size;
     c->geom = QsGeom{cfg->size, cfg->res, cfg->ox, cfg->oy, cfg->min_dist, cfg->max_dist, 1.0 / cfg->res};
     {   // landmark buckets: edge a hair above the closure radius, so that two points closer than the
-        // radius are never two buckets apart whatever the rounding of (v - b0) / cell
+        // radius are never two buckets apart whatever the rounding of (v - b0) / cell.  The directory is a
+        // hash table over the cells, sized for one entry per cell of the configured world (2^20 at most).
         const double cell = cfg->closure_radius > 0 ? cfg->closure_radius * (1.0 + 1e-9) : 1.0;
-        const double margin = 2.0 * cell, extent = cfg->size * cfg->res + 2.0 * margin;
-        double nbd = ceil(extent / cell);
+        double nbd = ceil(cfg->size * cfg->res / cell) + 1.0;
         if (!(nbd >= 1)) nbd = 1;
-        if (nbd > QS_MAX_BUCKETS_1D) nbd = QS_MAX_BUCKETS_1D;
-        c->bg = QsBucketGeom{cfg->ox - margin, cfg->oy - margin, cell, 1.0 / cell, (int)nbd, (int)nbd};
-        c->dir_entries = (size_t)QS_NTYPES * (size_t)c->bg.nbx * (size_t)c->bg.nby;
+        if (nbd > 1024) nbd = 1024;
+        unsigned int slab = 256;
+        while ((double)slab < nbd * nbd) slab <<= 1;
+        c->bg = QsBucketGeom{cfg->ox, cfg->oy, cell, 1.0 / cell, slab - 1, 0};
+        c->dir_entries = (size_t)QS_NTYPES * slab;
     }
     const int nb = cfg->max_agent + 1;
 #define CREATE_CHK(x) do { hipError_t e__ = (x); if (e__ != hipSuccess) { int rc__ = qs_fail(nullptr, QS_E_HIP, #x, e__); qs_destroy(c); return rc__; } } while (0)

@@ -32,15 +32,14 @@ __host__ __device__ inline double qs_double_from_ord(unsigned long long k)
 
 // ---- per pose-graph device state (PoseGraphSLAM, dual_bot_mapper.py:261-271) -------------
 // The landmark list is kept twice: as the reference's insertion-ordered log (read-back, and
-// the fallback scan), and as a spatial index: a directory of buckets of edge >= CLOSURE_RADIUS
-// per landmark type, each bucket a chain of 7-entry nodes in insertion order.  A query looks at
+// the fallback scan), and as a spatial index: a directory (hash table over the bucket cells) of buckets
+// of edge >= CLOSURE_RADIUS per landmark type, each bucket a chain of 7-entry nodes in insertion order.  A query looks at
 // the 3x3 buckets around it; the first match in list order is the lowest node index among them.
 #define QS_NTYPES 5               // landmark types 1..5 are indexed (LM_CORNER_L..LM_OPEN, :68-74)
 #define QS_NODE_CAP 7
-#define QS_MAX_BUCKETS_1D 2048
 struct alignas(64) QsLmNode { long long idx[8]; double x[8]; double y[8]; };   // idx 0x7f7f.. = empty slot
 struct QsDirEntry { unsigned int head, tail, tail_cnt, pad; };                  // head 0 = empty bucket
-struct QsBucketGeom { double bx0, by0, cell, inv_cell; int nbx, nby; };
+struct QsBucketGeom { double bx0, by0, cell, inv_cell; unsigned int hmask, pad; };   // hmask + 1 = table entries per type
 
 struct QsGraphDev {
     long long n_nodes;     // len(self.nodes)
@@ -52,7 +51,7 @@ struct QsGraphDev {
     unsigned char *lm_type;
     long long *cl_lm_idx, *cl_node_idx;
     double *cl_dx, *cl_dy;
-    QsDirEntry *dir;       // [QS_NTYPES][nby][nbx]
+    QsDirEntry *dir;       // [QS_NTYPES][hmask + 1]
     QsLmNode *nodes;       // [cap_lms + 1]; node 0 is the null node
     unsigned int *nd_next; // [cap_lms + 1]
     unsigned int *misc;    // [cap_lms] log slots of landmarks the directory does not cover
@@ -135,7 +134,7 @@ struct qs_ctx {
     QsBatch b{};
     QsSlamBatch sb{};
     QsBucketGeom bg{};
-    size_t dir_entries = 0;      // QS_NTYPES * nbx * nby
+    size_t dir_entries = 0;      // QS_NTYPES * (hmask + 1)
     size_t last_n = 0;
     bool last_has_poses = false;
 

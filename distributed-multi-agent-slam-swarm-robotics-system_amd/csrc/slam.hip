@@ -8,7 +8,7 @@
 //
 //   index  (parallel)  node index of every accepted record inside its pose graph (a stable
 //                      partition by graph) and the compacted list of landmark events per graph;
-//   chain  (one wave per graph) walks ONLY the landmark events, in node order, in windows;
+//   chain  (one workgroup per graph) walks ONLY the landmark events, in node order, in windows;
 //   pose   (parallel)  every record's pose = raw + drift of its bot at that node, looked up in
 //                      the bot's closure list of the batch.
 //
@@ -21,10 +21,10 @@
 //   (2) landmarks are appended in node order (:288), so "idx - lm_idx >= MIN" selects a prefix
 //       and the first match in list order is the LOWEST node index among the matches.
 // The match search uses the spatial index of QsGraphDev: buckets of edge >= CLOSURE_RADIUS per
-// landmark type, entries in insertion order; the 3x3 buckets around a query contain every
-// landmark within the radius, and the minimum node index over their first matches is the
-// reference's first match.  Landmarks the directory does not cover (type > 5, or outside the
-// bucket grid) live in a side list that every query also scans.
+// landmark type (a hash table over the bucket cells: any pose has its bucket), entries in insertion
+// order; the 3x3 buckets around a query contain every landmark within the radius, and the minimum
+// node index over their first matches is the reference's first match.  Landmarks of a type the
+// directory has no slab for (type > 5) live in a side list that every query also scans.
 #include "qs_internal.h"
 
 #define LL_MAX 0x7fffffffffffffffll
@@ -186,21 +186,24 @@ __device__ inline long long rl64(long long v, int src_lane)      // wave-uniform
     return ((long long)hi << 32) | (unsigned int)lo;
 }
 
-// bucket key of the 3x3 centre and the mask of neighbours that exist in the directory.  Points outside
-// the bucket grid go to its border buckets: clamping never moves two coordinates further apart, so two
-// points closer than the radius are still at most one bucket apart (only landmark types the directory
-// has no slab for end up in the side list).
-__device__ inline void bucket_prepare(double x, double y, int type, const QsBucketGeom &bg, long long dir_slab,
-                                      long long &kb, unsigned int &nbmask)
+// The directory is a hash table over the bucket cells (cx, cy), one slab per landmark type: any pose has
+// its bucket, inside the configured world or not, and a drifting graph does not pile up at a border.  Two
+// cells that share a table entry share a chain (still in node order); the distance test sorts them out.
+__device__ inline unsigned int bucket_hash(int cx, int cy, unsigned int hmask)
 {
-    kb = -1; nbmask = 0;
-    if (type < 1 || type > QS_NTYPES) return;
-    const int cx = min(max(bucket_coord(x, bg.bx0, bg.inv_cell), 0), bg.nbx - 1);
-    const int cy = min(max(bucket_coord(y, bg.by0, bg.inv_cell), 0), bg.nby - 1);
-    kb = (type - 1) * dir_slab + (long long)(cy * bg.nbx + cx);        // |cy * nbx + cx| < 2^23: buckets per axis <= 2048
-    // bit q = 3 * (dy + 1) + (dx + 1) is set when neighbour (cx + dx, cy + dy) exists
-    const unsigned int xm = (cx >= 1 ? 1u : 0u) | 2u | (cx + 1 < bg.nbx ? 4u : 0u);
-    nbmask = (cy >= 1 ? xm : 0u) | (xm << 3) | (cy + 1 < bg.nby ? xm << 6 : 0u);
+    unsigned int h = ((unsigned int)cx * 0x9E3779B1u) ^ ((unsigned int)cy * 0x85EBCA77u);
+    h ^= h >> 15;
+    return h & hmask;
+}
+// cell of a pose; false: a landmark type the directory has no slab for (side list)
+__device__ inline bool bucket_cell(double x, double y, int type, const QsBucketGeom &bg, int &cx, int &cy)
+{
+    cx = bucket_coord(x, bg.bx0, bg.inv_cell); cy = bucket_coord(y, bg.by0, bg.inv_cell);
+    return type >= 1 && type <= QS_NTYPES;
+}
+__device__ inline long long bucket_key(int type, int cx, int cy, const QsBucketGeom &bg)
+{
+    return (long long)(type - 1) * ((long long)bg.hmask + 1) + bucket_hash(cx, cy, bg.hmask);
 }
 
 
@@ -263,15 +266,15 @@ __device__ inline void chain_insert_lanes(const QsGraphDev &G, bool inw, int ran
 // flight.  Those queries read the index for everything older and the LDS arrays for this window, so
 // nothing waits for these stores; they are complete (vmcnt) before the barrier that ends the phase,
 // i.e. before the window after next looks for them in HBM.
-__device__ inline void chain_insert_window(const QsGraphDev &G, const QsBucketGeom &bg, long long dir_slab, const long long *i_idx,
+__device__ inline void chain_insert_window(const QsGraphDev &G, const QsBucketGeom &bg, const long long *i_idx,
                                            const double *i_x, const double *i_y, const int *i_type, int k, int lane,
                                            long long &n_lms, long long &n_misc, unsigned int &pool)
 {
     const long long idx = lane < 32 ? i_idx[lane] : LL_MAX;
     const double x = lane < 32 ? i_x[lane] : 0, y = lane < 32 ? i_y[lane] : 0;
     const int type = lane < k ? i_type[lane] : 0;
-    long long kb; unsigned int nbm;
-    bucket_prepare(x, y, type, bg, dir_slab, kb, nbm);          // kb < 0: a type without a slab (side list)
+    int cx, cy;
+    const long long kb = bucket_cell(x, y, type, bg, cx, cy) ? bucket_key(type, cx, cy, bg) : -1;   // -1: side list
     chain_insert_lanes(G, lane < k, lane, idx, kb, x, y, type, k, lane, n_lms, n_misc, pool);
 }
 
@@ -389,7 +392,6 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
     }
 
     const unsigned int e0 = sb.ev_base[g], e1 = sb.ev_base[g + 1];
-    const long long dir_slab = (long long)bg.nbx * bg.nby;
 
     if (wave == CH_WAVES - 1 && lane < 32) {
         const bool have = e0 + lane < e1;
@@ -501,7 +503,7 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
             const ChWindow W = chain_window(n_idx[par], n_a[par], active, e, e1, lane, win);
             if (have_prev) {
                 if (s_ik[par ^ 1] > 0) {
-                    chain_insert_window(G, bg, dir_slab, i_idx[par ^ 1], i_x[par ^ 1], i_y[par ^ 1], i_type[par ^ 1], s_ik[par ^ 1], lane,
+                    chain_insert_window(G, bg, i_idx[par ^ 1], i_x[par ^ 1], i_y[par ^ 1], i_type[par ^ 1], s_ik[par ^ 1], lane,
                                         n_lms, n_misc, pool);
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the stores are done before the phase ends ...
                     if (lane == 0) s_nmisc = n_misc;                         // ... and before the side list's new length shows
@@ -530,7 +532,7 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
         // scan is three coalesced row loads (idx, x, y of 9 nodes)
         const int nbk = lane / QS_NODE_CAP, se = lane % QS_NODE_CAP;
         const int last_lane = min(nbk * QS_NODE_CAP + QS_NODE_CAP - 1, 63);
-        const long long nb_off = ((nbk / 3) - 1) * (long long)bg.nbx + (nbk % 3) - 1;
+        const int nb_dx = (nbk % 3) - 1, nb_dy = (nbk / 3) - 1;        // the lane's neighbour of the 3x3
         unsigned long long st_rounds = 0, st_iters = 0, st_misc = 0;
 #if defined(QS_CHAIN_PROF) || defined(QS_CHAIN_PROF3) || defined(QS_CHAIN_PROF5)
         unsigned long long pq_a = 0, pq_b = 0, pq_c = 0, pq_d = 0;
@@ -570,10 +572,10 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
                 long long li = LL_MAX; double lx = 0, ly = 0; int lt = 0;
                 if (lane < 32) { li = i_idx[par ^ 1][lane]; lx = i_x[par ^ 1][lane]; ly = i_y[par ^ 1][lane]; lt = i_type[par ^ 1][lane]; }
                 const long long nm = s_nmisc;
-                long long qkb; unsigned int qnbm;
-                bucket_prepare(qx, qy, qtype, bg, dir_slab, qkb, qnbm);
+                int qcx, qcy;
+                const bool indexed = bucket_cell(qx, qy, qtype, bg, qcx, qcy);
                 unsigned int node = 0;
-                if (lane < 9 * QS_NODE_CAP && ((qnbm >> nbk) & 1u)) node = g_dir[qkb + nb_off].head;
+                if (indexed && lane < 9 * QS_NODE_CAP) node = g_dir[bucket_key(qtype, qcx + nb_dx, qcy + nb_dy, bg)].head;
                 long long best = LL_MAX, gbest = LL_MAX;
                 double bx = 0, by = 0;
                 st_rounds++;
