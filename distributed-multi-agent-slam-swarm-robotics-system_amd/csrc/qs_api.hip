@@ -83,24 +83,30 @@ static hipError_t grow_array(T **p, long long old_n, long long new_cap, hipStrea
     return hipSuccess;
 }
 
-// node pool: entries are "empty" (idx bytes 0x7f -> a huge node index) and unlinked (next 0)
+// nodes (first node of every directory entry + the overflow pool): "empty" (idx bytes 0x7f -> a huge node
+// index) and unlinked (next 0)
 static hipError_t grow_pool(qs_ctx *c, QsGraphDev &G, long long old_cap, long long new_cap)
 {
+    const size_t fixed = 1 + c->dir_entries, n_new = fixed + (size_t)new_cap, n_old = fixed + (size_t)old_cap;
     QsLmNode *nodes = nullptr; unsigned int *next = nullptr, *misc = nullptr;
-    hipError_t e = hipMalloc((void **)&nodes, (size_t)(new_cap + 1) * sizeof(QsLmNode));
-    if (e == hipSuccess) e = hipMalloc((void **)&next, (size_t)(new_cap + 1) * sizeof(unsigned int));
+    hipError_t e = hipMalloc((void **)&nodes, n_new * sizeof(QsLmNode));
+    if (e == hipSuccess) e = hipMalloc((void **)&next, n_new * sizeof(unsigned int));
     if (e == hipSuccess) e = hipMalloc((void **)&misc, (size_t)new_cap * sizeof(unsigned int));
-    if (e == hipSuccess) e = hipMemsetAsync(nodes, 0x7f, (size_t)(new_cap + 1) * sizeof(QsLmNode), c->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(next, 0, (size_t)(new_cap + 1) * sizeof(unsigned int), c->stream);
-    if (e == hipSuccess && G.nodes && old_cap > 0) {
-        e = hipMemcpyAsync(nodes, G.nodes, (size_t)(old_cap + 1) * sizeof(QsLmNode), hipMemcpyDeviceToDevice, c->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(next, G.nd_next, (size_t)(old_cap + 1) * sizeof(unsigned int), hipMemcpyDeviceToDevice, c->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(misc, G.misc, (size_t)old_cap * sizeof(unsigned int), hipMemcpyDeviceToDevice, c->stream);
+    if (e == hipSuccess && G.nodes) {
+        e = hipMemsetAsync(nodes + n_old, 0x7f, (n_new - n_old) * sizeof(QsLmNode), c->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(next + n_old, 0, (n_new - n_old) * sizeof(unsigned int), c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(nodes, G.nodes, n_old * sizeof(QsLmNode), hipMemcpyDeviceToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(next, G.nd_next, n_old * sizeof(unsigned int), hipMemcpyDeviceToDevice, c->stream);
+        if (e == hipSuccess && old_cap > 0) e = hipMemcpyAsync(misc, G.misc, (size_t)old_cap * sizeof(unsigned int), hipMemcpyDeviceToDevice, c->stream);
+    } else if (e == hipSuccess) {
+        e = hipMemsetAsync(nodes, 0x7f, n_new * sizeof(QsLmNode), c->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(next, 0, n_new * sizeof(unsigned int), c->stream);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) { hipFree(nodes); hipFree(next); hipFree(misc); return e; }
     hipFree(G.nodes); hipFree(G.nd_next); hipFree(G.misc);
     G.nodes = nodes; G.nd_next = next; G.misc = misc;
+    G.node_cap = (long long)n_new;
     return hipSuccess;
 }
 
@@ -140,7 +146,7 @@ static int graph_reserve(qs_ctx *c, int g, long long need_lms, long long need_cl
         HIPCHK(c, hipStreamSynchronize(c->stream));
         QsGraphDev upd = G;
         upd.n_nodes = cur.n_nodes; upd.n_lms = cur.n_lms; upd.n_cls = cur.n_cls;
-        upd.n_misc = cur.n_misc; upd.nodes_used = cur.nodes_used ? cur.nodes_used : 1;
+        upd.n_misc = cur.n_misc; upd.nodes_used = cur.nodes_used ? cur.nodes_used : (unsigned int)(1 + c->dir_entries);
         HIPCHK(c, hipMemcpyAsync(c->d_graphs + g, &upd, sizeof upd, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
@@ -160,14 +166,14 @@ static int reset_state(qs_ctx *c)
     HIPCHK(c, hipMemsetAsync(c->d_graph_batch, 0, (size_t)c->n_graphs * 2 * sizeof(unsigned long long), c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_ekf, 0, (size_t)nb * 44 * sizeof(double), c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_ekf_prev, 0, (size_t)nb * 4 * sizeof(double), c->stream));
+    // the bucket index of every graph: only what the session used of it (directory entries, first nodes,
+    // pool nodes), found from the landmark log on the device -- before the counters are zeroed below
+    HIPCHK(c, qs_launch_slam_reset_index(c));
     std::vector<QsGraphDev> upd(c->h_graphs);
     for (int g = 0; g < c->n_graphs; g++) {
         upd[g].n_nodes = upd[g].n_lms = upd[g].n_cls = 0;
-        upd[g].n_misc = 0; upd[g].nodes_used = 1;
+        upd[g].n_misc = 0; upd[g].nodes_used = (unsigned int)(1 + c->dir_entries);
         c->lms_upper[g] = 0; c->cls_upper[g] = 0;
-        HIPCHK(c, hipMemsetAsync(upd[g].dir, 0, c->dir_entries * sizeof(QsDirEntry), c->stream));
-        HIPCHK(c, hipMemsetAsync(upd[g].nodes, 0x7f, (size_t)(upd[g].cap_lms + 1) * sizeof(QsLmNode), c->stream));
-        HIPCHK(c, hipMemsetAsync(upd[g].nd_next, 0, (size_t)(upd[g].cap_lms + 1) * sizeof(unsigned int), c->stream));
     }
     HIPCHK(c, hipMemcpyAsync(c->d_graphs, upd.data(), upd.size() * sizeof(QsGraphDev), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));   // lc / upd are host temporaries

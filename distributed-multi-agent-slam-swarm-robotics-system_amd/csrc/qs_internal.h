@@ -38,7 +38,7 @@ __host__ __device__ inline double qs_double_from_ord(unsigned long long k)
 #define QS_NTYPES 5               // landmark types 1..5 are indexed (LM_CORNER_L..LM_OPEN, :68-74)
 #define QS_NODE_CAP 7
 struct alignas(64) QsLmNode { long long idx[8]; double x[8]; double y[8]; };   // idx 0x7f7f.. = empty slot
-struct QsDirEntry { unsigned int head, tail, tail_cnt, pad; };                  // head 0 = empty bucket
+struct QsDirEntry { unsigned int head, tail, tail_cnt, pad; };                  // head 0 = empty bucket (insert-side bookkeeping)
 struct QsBucketGeom { double bx0, by0, cell, inv_cell; unsigned int hmask, pad; };   // hmask + 1 = table entries per type
 
 struct QsGraphDev {
@@ -52,11 +52,13 @@ struct QsGraphDev {
     long long *cl_lm_idx, *cl_node_idx;
     double *cl_dx, *cl_dy;
     QsDirEntry *dir;       // [QS_NTYPES][hmask + 1]
-    QsLmNode *nodes;       // [cap_lms + 1]; node 0 is the null node
-    unsigned int *nd_next; // [cap_lms + 1]
+    QsLmNode *nodes;       // [node_cap]: node 0 is the null node, node 1 + t the FIRST node of directory entry t (a query
+                           // goes straight to it: no directory round trip), the pool of overflow nodes after those
+    unsigned int *nd_next; // [node_cap]
     unsigned int *misc;    // [cap_lms] log slots of landmarks the directory does not cover
     long long n_misc;
-    unsigned int nodes_used, pad0;
+    unsigned int nodes_used, pad0;   // next free pool node
+    long long node_cap;    // 1 + directory entries + cap_lms
 };
 
 // ---- per-batch scratch of the SLAM stage ---------------------------------------------------
@@ -161,6 +163,7 @@ hipError_t qs_launch_decode(qs_ctx *c, const unsigned char *d_pkts, size_t n, si
 #define QS_SLAM_IDX_BLOCK 1024   // records per block of the SLAM index tables
 // slam.hip
 hipError_t qs_launch_slam(qs_ctx *c, size_t n, bool raw_pose = false);
+hipError_t qs_launch_slam_reset_index(qs_ctx *c);              // empties the bucket index of every graph (what was used of it)
 int qs_slam_blocks(size_t n);
 // raycast.hip
 #define QS_DIRECT_MAX_BATCH 256   // raycast_mode auto: batches up to this size take the direct kernel

@@ -233,12 +233,14 @@ __device__ inline void chain_insert_lanes(const QsGraphDev &G, bool inw, int ran
         const long long kk = rl64(key, ld);
         const unsigned long long grp = __ballot(inb && key == kk);
         const int gsize = __popcll(grp);
-        const unsigned int head = __builtin_amdgcn_readlane(de.head, ld), tail = __builtin_amdgcn_readlane(de.tail, ld);
-        const unsigned int tc = head ? __builtin_amdgcn_readlane(de.tail_cnt, ld) : QS_NODE_CAP;   // no tail node yet: "full"
+        // an empty bucket's tail is its first node, the one that belongs to the directory entry
+        const unsigned int head = __builtin_amdgcn_readlane(de.head, ld);
+        const unsigned int tail = head ? __builtin_amdgcn_readlane(de.tail, ld) : 1u + (unsigned int)kk;
+        const unsigned int tc = head ? __builtin_amdgcn_readlane(de.tail_cnt, ld) : 0u;
         const unsigned int total = tc + gsize;
         const unsigned int nn = total > QS_NODE_CAP ? (total - QS_NODE_CAP + QS_NODE_CAP - 1) / QS_NODE_CAP : 0;
         const unsigned int base = pool;
-        if (inb && key == kk && (long long)base + nn <= G.cap_lms) {
+        if (inb && key == kk && (long long)base + nn <= G.node_cap) {
             const unsigned int p = tc + __popcll(grp & ((1ull << lane) - 1));
             const unsigned int nd = p < QS_NODE_CAP ? tail : base + (p - QS_NODE_CAP) / QS_NODE_CAP;
             const unsigned int sl = p < QS_NODE_CAP ? p : (p - QS_NODE_CAP) % QS_NODE_CAP;
@@ -246,10 +248,10 @@ __device__ inline void chain_insert_lanes(const QsGraphDev &G, bool inw, int ran
             np->idx[sl] = idx; np->x[sl] = x; np->y[sl] = y;
             if (lane == ld) {
                 QsDirEntry upd;
-                upd.head = head; upd.tail = tail; upd.tail_cnt = total; upd.pad = 0;
+                upd.head = 1u + (unsigned int)kk; upd.tail = tail; upd.tail_cnt = total; upd.pad = 0;
                 if (nn) {
                     for (unsigned int q = 0; q + 1 < nn; q++) G.nd_next[base + q] = base + q + 1;
-                    if (head) G.nd_next[tail] = base; else upd.head = base;
+                    G.nd_next[tail] = base;
                     upd.tail = base + nn - 1;
                     upd.tail_cnt = total - QS_NODE_CAP * nn;
                 }
@@ -283,7 +285,6 @@ __device__ inline void chain_insert_window(const QsGraphDev &G, const QsBucketGe
 // also wait for the node rows in flight.  The query waves read the index through global pointers.
 #define QS_GLOBAL __attribute__((address_space(1)))
 typedef const QS_GLOBAL QsLmNode *QsNodeG;
-typedef const QS_GLOBAL QsDirEntry *QsDirG;
 typedef const QS_GLOBAL unsigned int *QsU32G;
 
 // wave-uniform read of one lane of a double
@@ -526,7 +527,6 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
         long long c_last = 0;
         if (own < nb) { c_dx = s_dx[0][own]; c_dy = s_dy[0][own]; c_last = s_lastc[0][own]; }
         const QsNodeG g_nodes = (QsNodeG)Gp->nodes;
-        const QsDirG g_dir = (QsDirG)Gp->dir;
         const QsU32G g_next = (QsU32G)Gp->nd_next;
         // lane = (bucket of the 3x3 neighbourhood, entry of that bucket's current 7-entry node): a node
         // scan is three coalesced row loads (idx, x, y of 9 nodes)
@@ -575,7 +575,7 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
                 int qcx, qcy;
                 const bool indexed = bucket_cell(qx, qy, qtype, bg, qcx, qcy);
                 unsigned int node = 0;
-                if (indexed && lane < 9 * QS_NODE_CAP) node = g_dir[bucket_key(qtype, qcx + nb_dx, qcy + nb_dy, bg)].head;
+                if (indexed && lane < 9 * QS_NODE_CAP) node = 1u + (unsigned int)bucket_key(qtype, qcx + nb_dx, qcy + nb_dy, bg);   // the entry's own first node
                 long long best = LL_MAX, gbest = LL_MAX;
                 double bx = 0, by = 0;
                 st_rounds++;
@@ -754,6 +754,45 @@ qs_slam_pose_kernel(size_t n, QsBatch b, QsSlamBatch sb)
     else { dx = sb.acl_dx[base + lo - 1]; dy = sb.acl_dy[base + lo - 1]; }
     b.rx[i] = b.px[i] + dx;
     b.ry[i] = b.py[i] + dy;
+}
+
+// ---- reset: empties what a session used of the bucket index ------------------------------------------
+// The first node of every directory entry makes the node array as large as the table (>100 MB per graph
+// for a 4096^2 world): a reset clears only the entries the landmark log names -- the log keeps the pose
+// each landmark was indexed at -- and the pool nodes that were handed out.
+__global__ void __launch_bounds__(256)
+qs_slam_reset_index_kernel(const QsGraphDev *__restrict__ graphs, QsBucketGeom bg, unsigned int first_pool)
+{
+    const QsGraphDev G = graphs[blockIdx.y];
+    if (!G.nodes) return;
+    const long long n_lms = G.n_lms < G.cap_lms ? G.n_lms : G.cap_lms;
+    const long long pool_n = (long long)G.nodes_used - first_pool;
+    const long long total = (n_lms + (pool_n > 0 ? pool_n : 0)) * 32;          // 32 lanes per node: 24 words + next + directory entry
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+        const long long i = t >> 5;
+        const int r = (int)(t & 31);
+        long long node, key = -1;
+        if (i < n_lms) {
+            int cx, cy;
+            const int type = G.lm_type[i];
+            if (!bucket_cell(G.lm_x[i], G.lm_y[i], type, bg, cx, cy)) continue;     // side list: not in the index
+            key = bucket_key(type, cx, cy, bg);
+            node = 1 + key;
+        } else {
+            node = first_pool + (i - n_lms);
+        }
+        if (r < 24) ((unsigned long long *)(G.nodes + node))[r] = 0x7f7f7f7f7f7f7f7full;
+        else if (r == 24) G.nd_next[node] = 0;
+        else if (r == 25 && key >= 0) G.dir[key] = QsDirEntry{0, 0, 0, 0};
+    }
+}
+
+hipError_t qs_launch_slam_reset_index(qs_ctx *c)
+{
+    if (!c->d_graphs || c->n_graphs <= 0) return hipSuccess;
+    hipLaunchKernelGGL(qs_slam_reset_index_kernel, dim3(64, c->n_graphs), dim3(256), 0, c->stream, c->d_graphs, c->bg,
+                       (unsigned int)(1 + c->dir_entries));
+    return hipGetLastError();
 }
 
 hipError_t qs_launch_slam(qs_ctx *c, size_t n, bool raw_pose)
