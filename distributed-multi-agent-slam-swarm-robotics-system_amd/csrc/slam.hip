@@ -568,7 +568,7 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
                 const int qtype = __builtin_amdgcn_readlane(W.type, src);
                 const long long limit = qidx - min_between;                        // :300
                 // window V - 1 is not in the index yet: its landmarks (final poses) are in LDS, in node order.
-                // Read now, looked at in the shadow of the directory load.
+                // Read now, looked at in the shadow of the first node loads.
                 long long li = LL_MAX; double lx = 0, ly = 0; int lt = 0;
                 if (lane < 32) { li = i_idx[par ^ 1][lane]; lx = i_x[par ^ 1][lane]; ly = i_y[par ^ 1][lane]; lt = i_type[par ^ 1][lane]; }
                 const long long nm = s_nmisc;
@@ -581,19 +581,10 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
                 st_rounds++;
                 long long l_idx = LL_MAX;
                 double l_x = 0, l_y = 0;
-                {
-                    const double dx = qx - lx, dy = qy - ly;
-                    const bool cand = li <= limit && lt == qtype && dx * dx + dy * dy < r2thr;    // (li = LL_MAX: no landmark)
-                    const unsigned long long cm = __ballot(cand);
-                    if (cm) {
-                        const int w = __ffsll((long long)cm) - 1;
-                        l_idx = rl64(li, w); l_x = rlf64(lx, w); l_y = rlf64(ly, w);
-                    }
-                }
 #ifdef QS_CHAIN_PROF
                 const unsigned long long tq1 = __builtin_amdgcn_s_memtime();
 #endif
-                for (;;) {
+                for (bool first_scan = true;; first_scan = false) {
 #ifdef QS_CHAIN_PROF3
                     const unsigned long long u0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -609,6 +600,15 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
 #ifdef QS_CHAIN_PROF3
                     const unsigned long long u1 = __builtin_amdgcn_s_memtime();
 #endif
+                    if (first_scan) {
+                        const double dx = qx - lx, dy = qy - ly;
+                        const bool cand = li <= limit && lt == qtype && dx * dx + dy * dy < r2thr;    // (li = LL_MAX: no landmark)
+                        const unsigned long long cm = __ballot(cand);
+                        if (cm) {
+                            const int w = __ffsll((long long)cm) - 1;
+                            l_idx = rl64(li, w); l_x = rlf64(lx, w); l_y = rlf64(ly, w);
+                        }
+                    }
 #ifdef QS_CHAIN_PROF3
                     const unsigned long long u2 = __builtin_amdgcn_s_memtime();
                     asm volatile("s_waitcnt vmcnt(0)" :: "v"(id), "v"(nx), "v"(ny), "v"(nxt), "v"(lastid));
