@@ -624,7 +624,9 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
                         if (dx * dx + dy * dy < r2thr) { best = id; bx = nx; by = ny; newhit = true; }   // :308-309
                     }
                     if (__ballot(newhit)) {
-                        const long long v = wave_min_nonneg_i64(newhit ? best : LL_MAX);   // node indices are >= 0
+                        // node indices are >= 0, and those that match are <= limit: below 2^32 the low words decide
+                        const long long v = (unsigned long long)limit >> 32 ? wave_min_nonneg_i64(newhit ? best : LL_MAX)
+                                                                            : (long long)wave_min_u32(newhit ? (unsigned int)best : 0xffffffffu);
                         gbest = v < gbest ? v : gbest;
                     }
                     const unsigned long long hitm = __ballot(best != LL_MAX);
