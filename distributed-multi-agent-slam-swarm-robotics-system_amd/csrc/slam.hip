@@ -350,6 +350,9 @@ __device__ inline ChWindow chain_window(const long long *nidx, const int *na, bo
 // Nothing inside a phase waits for another wave: every LDS word has one writer per phase and its readers
 // come a barrier later.
 // Waves without a role leave at once (a barrier counts the waves still running).
+// ONE: at most CH_AGW bots per graph, i.e. one agent per owner (its state in lane 0): the agent -> owner /
+// lane arithmetic folds away.
+template <bool ONE>
 __global__ void __launch_bounds__(CH_THREADS)
 qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGeom bg, int bots_per_graph,
                      int max_agent, int win, int min_between, double r2thr, double corr,
@@ -545,16 +548,25 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
             unsigned long long v1 = 0, v2 = 0;
 #endif
             const ChWindow W = chain_window(n_idx[par], n_a[par], active, e, e1, lane, win, n_type[par], n_px[par], n_py[par]);
+#ifdef QS_CHAIN_PROF6
+            const unsigned long long vA = __builtin_amdgcn_s_memtime();
+#endif
             unsigned int done = 0;                      // bit a / CH_AGW: agent a has its match
             const double o_dx = rlf64(c_dx, 0), o_dy = rlf64(c_dy, 0);     // lane 0's agent: drift at window start
-            const bool ownlane = W.v_inw && (W.v_a % CH_AGW) + 1 == wave;
+            const bool ownlane = W.v_inw && (ONE ? W.v_a : W.v_a % CH_AGW) + 1 == wave;
+#ifdef QS_CHAIN_PROF6
+            unsigned long long vB = 0;
+#endif
             for (unsigned long long qrem = __ballot(ownlane); qrem; qrem &= qrem - 1) {
+#ifdef QS_CHAIN_PROF6
+                if (!vB) vB = __builtin_amdgcn_s_memtime();
+#endif
 #ifdef QS_CHAIN_PROF
                 const unsigned long long tq0 = __builtin_amdgcn_s_memtime();
 #endif
                 const int src = __ffsll((long long)qrem) - 1;
                 const int qa = __builtin_amdgcn_readlane(W.v_a, src);
-                const int ql = qa / CH_AGW;                                         // the lane that keeps agent qa's state
+                const int ql = ONE ? 0 : qa / CH_AGW;                               // the lane that keeps agent qa's state
                 if ((done >> ql) & 1u) continue;
                 const long long qidx = rl64(W.v_idx, src);
                 if (qidx - rl64(c_last, ql) < min_between) continue;                // :304
@@ -701,7 +713,7 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
             if (active && own < nb) { s_dx[par ^ 1][own] = c_dx; s_dy[par ^ 1][own] = c_dy; s_lastc[par ^ 1][own] = c_last; }
             // the window's landmarks get their final pose from their agent's owner: the drift at window start,
             // or -- later events of an agent that closed in this window -- the drift after the closure (:855-857)
-            if (nb <= CH_AGW) {                                           // one agent per owner: its state is in lane 0
+            if (ONE) {                                                    // one agent per owner: its state is in lane 0
                 const bool after = W.v_idx > rl64(c_last, 0);
                 const double ddx = after ? rlf64(c_dx, 0) : o_dx, ddy = after ? rlf64(c_dy, 0) : o_dy;
                 if (ownlane) { i_x[par][lane] = raw_pose ? W.px : W.px + ddx; i_y[par][lane] = raw_pose ? W.py : W.py + ddy; }
@@ -715,7 +727,11 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
 #ifdef QS_CHAIN_PROF5
             const unsigned long long v3 = __builtin_amdgcn_s_memtime();
             CH_PHASE_END(active, W.k);
+#ifdef QS_CHAIN_PROF6
+            if (v1 && v2) { pq_a += vA - v0; pq_b += vB - vA; pq_c += v1 - vB; }
+#else
             if (v1 && v2) { pq_a += v1 - v0; pq_b += v2 - v1; pq_c += v3 - v2; pq_d += __builtin_amdgcn_s_memtime() - v3; }
+#endif
 #else
             CH_PHASE_END(active, W.k);
 #endif
@@ -809,9 +825,14 @@ hipError_t qs_launch_slam(qs_ctx *c, size_t n, bool raw_pose)
     hipLaunchKernelGGL(qs_slam_prefix_kernel, dim3(1), dim3(256), 0, c->stream, sb, G, c->cfg.max_agent, c->d_drift);
     hipLaunchKernelGGL(qs_slam_index_kernel, dim3(sb.n_blocks), dim3(IDX_BLOCK), (size_t)IDX_WAVES * G * 2 * sizeof(unsigned int),
                        c->stream, n, c->b, sb, c->d_graphs, c->bots_per_graph, G);
-    hipLaunchKernelGGL(qs_slam_chain_kernel, dim3(G), dim3(CH_THREADS), 0, c->stream, c->d_graphs, sb, c->bg,
-                       c->bots_per_graph, c->cfg.max_agent, c->win, c->cfg.min_poses_between, c->r2_threshold,
-                       c->cfg.closure_correction, c->d_drift, c->d_last_closure, c->d_counters, raw_pose ? 1 : 0);
+    if (c->bots_per_graph <= CH_AGW)
+        hipLaunchKernelGGL(qs_slam_chain_kernel<true>, dim3(G), dim3(CH_THREADS), 0, c->stream, c->d_graphs, sb, c->bg,
+                           c->bots_per_graph, c->cfg.max_agent, c->win, c->cfg.min_poses_between, c->r2_threshold,
+                           c->cfg.closure_correction, c->d_drift, c->d_last_closure, c->d_counters, raw_pose ? 1 : 0);
+    else
+        hipLaunchKernelGGL(qs_slam_chain_kernel<false>, dim3(G), dim3(CH_THREADS), 0, c->stream, c->d_graphs, sb, c->bg,
+                           c->bots_per_graph, c->cfg.max_agent, c->win, c->cfg.min_poses_between, c->r2_threshold,
+                           c->cfg.closure_correction, c->d_drift, c->d_last_closure, c->d_counters, raw_pose ? 1 : 0);
     if (raw_pose) return hipGetLastError();
     hipLaunchKernelGGL(qs_slam_pose_kernel, dim3((unsigned int)((n + 255) / 256)), dim3(256), 0, c->stream, n, c->b, sb);
     return hipGetLastError();
