@@ -551,13 +551,16 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
 #ifdef QS_CHAIN_PROF6
             const unsigned long long vA = __builtin_amdgcn_s_memtime();
 #endif
-            unsigned int done = 0;                      // bit a / CH_AGW: agent a has its match
             const double o_dx = rlf64(c_dx, 0), o_dy = rlf64(c_dy, 0);     // lane 0's agent: drift at window start
             const bool ownlane = W.v_inw && (ONE ? W.v_a : W.v_a % CH_AGW) + 1 == wave;
+            // the lane's event may close if its agent is past its cool-down (:304); an agent that finds a match in
+            // this window takes its later events off the list, so the state at window start decides for all of them
+            const long long lane_last = ONE ? rl64(c_last, 0) : (ownlane ? s_lastc[par][W.v_a] : 0);
+            const bool may_close = ownlane && W.v_idx - lane_last >= min_between;
 #ifdef QS_CHAIN_PROF6
             unsigned long long vB = 0;
 #endif
-            for (unsigned long long qrem = __ballot(ownlane); qrem; qrem &= qrem - 1) {
+            for (unsigned long long qrem = __ballot(may_close); qrem; qrem &= qrem - 1) {
 #ifdef QS_CHAIN_PROF6
                 if (!vB) vB = __builtin_amdgcn_s_memtime();
 #endif
@@ -567,9 +570,7 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
                 const int src = __ffsll((long long)qrem) - 1;
                 const int qa = __builtin_amdgcn_readlane(W.v_a, src);
                 const int ql = ONE ? 0 : qa / CH_AGW;                               // the lane that keeps agent qa's state
-                if ((done >> ql) & 1u) continue;
                 const long long qidx = rl64(W.v_idx, src);
-                if (qidx - rl64(c_last, ql) < min_between) continue;                // :304
 #ifdef QS_CHAIN_PROF5
                 if (!v1) v1 = __builtin_amdgcn_s_memtime();
 #endif
@@ -693,7 +694,6 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
                 }
                 if (l_idx < gbest) { gbest = l_idx; wx = l_x; wy = l_y; }
                 if (gbest != LL_MAX) {
-                    done |= 1u << ql;
                     // the agent's later events cannot close (:304): off the wave's list (this one goes with the loop step)
                     qrem &= ~(__ballot(W.v_a == qa) & ~((2ull << src) - 1));
                     if (lane == 0) { w_ridx[par][src] = gbest; w_rx[par][src] = wx; w_ry[par][src] = wy; }
