@@ -472,7 +472,7 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
         if (lane == 0) {
             atomicAdd(&counters[QS_CNT_CLOSURES], (unsigned long long)(n_cls - n_cls0));
             atomicAdd(&counters[QS_CNT_SLAM_WINDOWS], st_windows);
-#if !defined(QS_CHAIN_PROF) && !defined(QS_CHAIN_PROF3) && !defined(QS_CHAIN_PROF5)
+#ifndef QS_CHAIN_PROF
             atomicAdd(&counters[QS_CNT_SLAM_CYC_A], st_a); atomicAdd(&counters[QS_CNT_SLAM_CYC_B], st_b);
 #endif
             atomicAdd(&counters[QS_CNT_SLAM_CYCLES], __builtin_amdgcn_s_memtime() - t0_cyc);
@@ -537,33 +537,20 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
         const int last_lane = min(nbk * QS_NODE_CAP + QS_NODE_CAP - 1, 63);
         const int nb_dx = (nbk % 3) - 1, nb_dy = (nbk / 3) - 1;        // the lane's neighbour of the 3x3
         unsigned long long st_rounds = 0, st_iters = 0, st_misc = 0;
-#if defined(QS_CHAIN_PROF) || defined(QS_CHAIN_PROF3) || defined(QS_CHAIN_PROF5)
-        unsigned long long pq_a = 0, pq_b = 0, pq_c = 0, pq_d = 0;
+#ifdef QS_CHAIN_PROF
+        unsigned long long pq_a = 0, pq_b = 0, pq_c = 0;
 #endif
         for (;;) {
             const bool active = e < e1;
             if (!active && !have_prev) break;
-#ifdef QS_CHAIN_PROF5
-            const unsigned long long v0 = __builtin_amdgcn_s_memtime();
-            unsigned long long v1 = 0, v2 = 0;
-#endif
             const ChWindow W = chain_window(n_idx[par], n_a[par], active, e, e1, lane, win, n_type[par], n_px[par], n_py[par]);
-#ifdef QS_CHAIN_PROF6
-            const unsigned long long vA = __builtin_amdgcn_s_memtime();
-#endif
             const double o_dx = rlf64(c_dx, 0), o_dy = rlf64(c_dy, 0);     // lane 0's agent: drift at window start
             const bool ownlane = W.v_inw && (ONE ? W.v_a : W.v_a % CH_AGW) + 1 == wave;
             // the lane's event may close if its agent is past its cool-down (:304); an agent that finds a match in
             // this window takes its later events off the list, so the state at window start decides for all of them
             const long long lane_last = ONE ? rl64(c_last, 0) : (ownlane ? s_lastc[par][W.v_a] : 0);
             const bool may_close = ownlane && W.v_idx - lane_last >= min_between;
-#ifdef QS_CHAIN_PROF6
-            unsigned long long vB = 0;
-#endif
             for (unsigned long long qrem = __ballot(may_close); qrem; qrem &= qrem - 1) {
-#ifdef QS_CHAIN_PROF6
-                if (!vB) vB = __builtin_amdgcn_s_memtime();
-#endif
 #ifdef QS_CHAIN_PROF
                 const unsigned long long tq0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -571,9 +558,6 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
                 const int qa = __builtin_amdgcn_readlane(W.v_a, src);
                 const int ql = ONE ? 0 : qa / CH_AGW;                               // the lane that keeps agent qa's state
                 const long long qidx = rl64(W.v_idx, src);
-#ifdef QS_CHAIN_PROF5
-                if (!v1) v1 = __builtin_amdgcn_s_memtime();
-#endif
                 const double odx = rlf64(c_dx, ql), ody = rlf64(c_dy, ql);
                 const double spx = rlf64(W.px, src), spy = rlf64(W.py, src);
                 const double qx = raw_pose ? spx : spx + odx;                         // rx += cdx  :856
@@ -598,9 +582,6 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
                 const unsigned long long tq1 = __builtin_amdgcn_s_memtime();
 #endif
                 for (bool first_scan = true;; first_scan = false) {
-#ifdef QS_CHAIN_PROF3
-                    const unsigned long long u0 = __builtin_amdgcn_s_memtime();
-#endif
                     const bool anyn = __ballot(node != 0) != 0;
                     long long id = LL_MAX;
                     double nx = 0, ny = 0;
@@ -610,9 +591,6 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
                         const QsNodeG nd = g_nodes + node;
                         id = nd->idx[se]; lastid = nd->idx[QS_NODE_CAP - 1]; nx = nd->x[se]; ny = nd->y[se]; nxt = g_next[node];
                     }
-#ifdef QS_CHAIN_PROF3
-                    const unsigned long long u1 = __builtin_amdgcn_s_memtime();
-#endif
                     if (first_scan) {
                         const double dx = qx - lx, dy = qy - ly;
                         const bool cand = li <= limit && lt == qtype && dx * dx + dy * dy < r2thr;    // (li = LL_MAX: no landmark)
@@ -622,12 +600,6 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
                             l_idx = rl64(li, w); l_x = rlf64(lx, w); l_y = rlf64(ly, w);
                         }
                     }
-#ifdef QS_CHAIN_PROF3
-                    const unsigned long long u2 = __builtin_amdgcn_s_memtime();
-                    asm volatile("s_waitcnt vmcnt(0)" :: "v"(id), "v"(nx), "v"(ny), "v"(nxt), "v"(lastid));
-                    const unsigned long long u3 = __builtin_amdgcn_s_memtime();
-                    pq_a += u1 - u0; pq_b += u2 - u1; pq_c += u3 - u2;
-#endif
                     if (!anyn) break;
                     st_iters++;
                     const bool inlim = node != 0 && id <= limit;      // empty slots read as a huge index
@@ -649,9 +621,6 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
                     const bool b_hit = ((hitm >> (nbk * QS_NODE_CAP)) & 0x7full) != 0;
                     const bool b_full = ((limm >> last_lane) & 1ull) != 0;
                     if (node) node = (b_hit || !b_full || nxt == 0 || lastid >= gbest) ? 0u : nxt;
-#ifdef QS_CHAIN_PROF3
-                    pq_d += __builtin_amdgcn_s_memtime() - u3;
-#endif
                 }
 #ifdef QS_CHAIN_PROF
                 const unsigned long long tq2 = __builtin_amdgcn_s_memtime();
@@ -703,9 +672,6 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
                     const double ndx = odx + cdx, ndy = ody + cdy;                             // :911-914
                     if (lane == ql) { c_dx = ndx; c_dy = ndy; c_last = qidx; }                 // :318
                 }
-#ifdef QS_CHAIN_PROF5
-                v2 = __builtin_amdgcn_s_memtime();
-#endif
 #ifdef QS_CHAIN_PROF
                 { const unsigned long long tq3 = __builtin_amdgcn_s_memtime(); pq_a += tq1 - tq0; pq_b += tq2 - tq1; pq_c += tq3 - tq2; }
 #endif
@@ -724,17 +690,7 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
                 i_x[par][lane] = raw_pose ? W.px : W.px + ddx;
                 i_y[par][lane] = raw_pose ? W.py : W.py + ddy;
             }
-#ifdef QS_CHAIN_PROF5
-            const unsigned long long v3 = __builtin_amdgcn_s_memtime();
             CH_PHASE_END(active, W.k);
-#ifdef QS_CHAIN_PROF6
-            if (v1 && v2) { pq_a += vA - v0; pq_b += vB - vA; pq_c += v1 - vB; }
-#else
-            if (v1 && v2) { pq_a += v1 - v0; pq_b += v2 - v1; pq_c += v3 - v2; pq_d += __builtin_amdgcn_s_memtime() - v3; }
-#endif
-#else
-            CH_PHASE_END(active, W.k);
-#endif
         }
         if (own < nb) {
             drift[2 * (bot0 + own)] = c_dx;
@@ -745,9 +701,8 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
             atomicAdd(&counters[QS_CNT_SLAM_ROUNDS], st_rounds);
             atomicAdd(&counters[QS_CNT_SLAM_NODE_ITERS], st_iters);
             atomicAdd(&counters[QS_CNT_SLAM_MISC_ITERS], st_misc);
-#if defined(QS_CHAIN_PROF) || defined(QS_CHAIN_PROF3) || defined(QS_CHAIN_PROF5)
+#ifdef QS_CHAIN_PROF
             atomicAdd(&counters[QS_CNT_SLAM_CYC_A], pq_a); atomicAdd(&counters[QS_CNT_SLAM_CYC_B], pq_b); atomicAdd(&counters[QS_CNT_SLAM_CYC_C], pq_c);
-            atomicAdd(&counters[QS_CNT_SLAM_MISC_ITERS], pq_d);
 #endif
         }
     }
