@@ -52,3 +52,36 @@ for it in range(n_iter):
         bad += 1
         print("MISMATCH", dict(it=it, size=size, res=res, ox=ox, oy=oy, sep=sep, n=n, mode=mode, ekf=ekf, cuts=cuts))
 print("fuzz done:", n_iter, "cases,", bad, "mismatches")
+
+# ---- loop-closure chain: many bots, graph partitions, closure constants, batch cuts -------------------
+bad2 = 0
+for it in range(n_iter):
+    nb = int(rng.choice([1, 2, 3, 5, 13, 14, 20, 40]))
+    bpg = int(rng.choice([0, 1, 2, 7, 13, 14]))
+    radius = float(rng.choice([0.6, 0.3, 1.0, 0.45]))
+    mb = int(rng.choice([30, 0, 1, 5, 31, 64]))
+    corr = float(rng.choice([0.5, 1.0, 0.1]))
+    n = int(rng.integers(2000, 24000))
+    stream = replay.multi_bot_stream(session, nb, n, pitch=float(rng.choice([8.0, 1.0, 0.2])), origin=(-8.0, -8.0), tiles_per_row=5)
+    o = orc.OracleMapper(512, 0.05, -12.8, -12.8, 0.0, max_agent=nb, bots_per_graph=bpg)
+    o.set_closure_params(radius, mb, corr)
+    o.feed_stream(stream)
+    cuts = sorted(set([0, n] + [int(c) for c in rng.integers(0, n, int(rng.integers(0, 4)))]))
+    with pkg.QuasarMapper(512, 0.05, -12.8, -12.8, max_agent=nb, bots_per_graph=bpg, closure_radius=radius,
+                          min_poses_between=mb, closure_correction=corr) as m:
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            m.ingest_array(stream[a:b])
+        ok = (m.grid_i8() == o.grid).all()
+        ng = 1 if bpg == 0 else -(-nb // bpg)
+        for g in range(ng):
+            idx, cc = m.closures(g); oi, oc = o.closures(g)
+            ok &= idx.shape == oi.shape and (idx == oi).all() and (len(oi) == 0 or np.abs(cc - oc).max() < 1e-9)
+            xy, ti = m.landmarks(g); oxy, oti = o.landmarks(g)
+            ok &= ti.shape == oti.shape and (ti == oti).all() and (len(oti) == 0 or np.abs(xy - oxy).max() < 1e-9)
+        for b in range(1, nb + 1):
+            ok &= np.allclose(m.drift(b), o.drift(b), rtol=0, atol=1e-9)
+    if not ok:
+        bad2 += 1
+        print("MISMATCH(slam)", dict(it=it, nb=nb, bpg=bpg, radius=radius, mb=mb, corr=corr, n=n, cuts=cuts))
+print("slam fuzz done:", n_iter, "cases,", bad2, "mismatches")
+sys.exit(1 if bad or bad2 else 0)
