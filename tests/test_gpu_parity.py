@@ -463,6 +463,35 @@ def test_64_bots_32_graphs_vs_oracle(pkg):
         assert (m.closures(0)[0] == o1.closures(0)[0]).all()
 
 
+@pytest.mark.parametrize("bpg", [1, 0, 20])
+def test_255_bots_graph_partitions(pkg, bpg):
+    """The protocol's maximum of 255 agents: one pose graph each (255 workgroups, 255 bucket indexes allocated
+    at their first packet), all in one graph (13 owner waves with up to 20 agents each), 13 graphs of 20."""
+    replay = _replay(pkg)
+    session, _ = replay.telemetry_csv_to_packets()
+    n = 255 * 500
+    stream = replay.multi_bot_stream(session, 255, n)
+    o = orc.OracleMapper(4096, 0.05, -102.4, -102.4, 0.0, max_agent=255, bots_per_graph=bpg)
+    assert o.feed_stream(stream) == n
+    with pkg.QuasarMapper(4096, 0.05, -102.4, -102.4, max_agent=255, bots_per_graph=bpg) as m:
+        m.ingest_array(stream[:30000]); m.ingest_array(stream[30000:])
+        assert (m.grid_i8() == o.grid).all()
+        total = 0
+        for gr in range(o.n_graphs):
+            idx, corr = m.closures(gr); oi, oc = o.closures(gr)
+            assert idx.shape == oi.shape and (idx == oi).all(), gr
+            if len(oi):
+                assert np.abs(corr - oc).max() < FLOAT_TOL
+            total += len(oi)
+        assert total > (500 if bpg == 1 else 10000)
+        for b in range(1, 256):
+            assert np.abs(m.drift(b) - o.drift(b)).max() < FLOAT_TOL
+        m.reset(); m.ingest_array(stream)                       # the index of every graph emptied and refilled
+        assert (m.grid_i8() == o.grid).all()
+        for gr in range(o.n_graphs):
+            assert (m.closures(gr)[0] == o.closures(gr)[0]).all()
+
+
 def test_device_buffer_aliasing_and_nccl_allreduce_single_rank(pkg):
     """The N>1 plumbing on one GPU: torch aliases the library's stamp / counter buffers through
     __cuda_array_interface__, and the RCCL all-reduce (world_size 1) runs on them in place."""
