@@ -544,6 +544,11 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
             const bool active = e < e1;
             if (!active && !have_prev) break;
             const ChWindow W = chain_window(n_idx[par], n_a[par], active, e, e1, lane, win, n_type[par], n_px[par], n_py[par]);
+            // window V - 1 is not in the index yet: its landmarks (final poses) are in LDS, in node order.  Read in
+            // the same LDS round trip as the events, looked at in the shadow of a query's first node loads.
+            long long li = LL_MAX; double lx = 0, ly = 0; int lt = 0;
+            if (lane < 32) { li = i_idx[par ^ 1][lane]; lx = i_x[par ^ 1][lane]; ly = i_y[par ^ 1][lane]; lt = i_type[par ^ 1][lane]; }
+            const long long nm = s_nmisc;
             const double o_dx = rlf64(c_dx, 0), o_dy = rlf64(c_dy, 0);     // lane 0's agent: drift at window start
             const bool ownlane = W.v_inw && (ONE ? W.v_a : W.v_a % CH_AGW) + 1 == wave;
             // the lane's event may close if its agent is past its cool-down (:304); an agent that finds a match in
@@ -564,11 +569,6 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
                 const double qy = raw_pose ? spy : spy + ody;                         // ry += cdy  :857
                 const int qtype = __builtin_amdgcn_readlane(W.type, src);
                 const long long limit = qidx - min_between;                        // :300
-                // window V - 1 is not in the index yet: its landmarks (final poses) are in LDS, in node order.
-                // Read now, looked at in the shadow of the first node loads.
-                long long li = LL_MAX; double lx = 0, ly = 0; int lt = 0;
-                if (lane < 32) { li = i_idx[par ^ 1][lane]; lx = i_x[par ^ 1][lane]; ly = i_y[par ^ 1][lane]; lt = i_type[par ^ 1][lane]; }
-                const long long nm = s_nmisc;
                 int qcx, qcy;
                 const bool indexed = bucket_cell(qx, qy, qtype, bg, qcx, qcy);
                 unsigned int node = 0;
