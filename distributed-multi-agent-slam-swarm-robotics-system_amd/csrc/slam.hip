@@ -525,6 +525,7 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
         // =================================== query waves ===================================
         // lane j keeps drift and last closure of agent (wave - 1) + CH_AGW * j -- the authoritative copy;
         // nothing else writes an agent's state
+        __builtin_amdgcn_s_setprio(3);             // the decisions are the critical path: ahead of the helper waves on a shared SIMD
         const int own = (wave - 1) + CH_AGW * lane;
         double c_dx = 0, c_dy = 0;
         long long c_last = 0;
