@@ -156,7 +156,10 @@ qs_slam_index_kernel(size_t n, QsBatch b, QsSlamBatch sb, const QsGraphDev *__re
 // number of instructions and LDS / memory round trips between one decision and the next.
 #define CH_WAVES 16
 #define CH_THREADS (CH_WAVES * QS_WAVE)
-#define CH_INS (CH_WAVES - 2)       // the wave that moves a committed window into the HBM index
+// (waves go to the four SIMDs round robin: with <= 2 owners the insert wave has SIMD 3 to itself, the light
+// fetch wave shares SIMD 2 with owner 2 -- the other way round costs 2 %)
+#define CH_INS (CH_WAVES - 1)       // the wave that moves a committed window into the HBM index
+#define CH_FETCH (CH_WAVES - 2)     // the wave that fetches the events
 #define CH_AGW (CH_WAVES - 3)       // query waves 1 .. CH_AGW: agent a belongs to wave 1 + a % CH_AGW
 
 // barrier that orders LDS traffic only (the two intra-window hand-offs go through LDS; a full
@@ -346,7 +349,7 @@ __device__ inline ChWindow chain_window(const long long *nidx, const int *na, bo
 //                   the closure itself (the arithmetic is wave 0's, on the same operands) to its agent's
 //                   state, and gives the agent's events in the window their final pose (LDS)
 //   wave CH_INS     moves window V - 1's landmarks into the index
-//   the last wave   fetches the events after window V.
+//   wave CH_FETCH   fetches the events after window V.
 // Nothing inside a phase waits for another wave: every LDS word has one writer per phase and its readers
 // come a barrier later.
 // Waves without a role leave at once (a barrier counts the waves still running).
@@ -397,7 +400,7 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
 
     const unsigned int e0 = sb.ev_base[g], e1 = sb.ev_base[g + 1];
 
-    if (wave == CH_WAVES - 1 && lane < 32) {
+    if (wave == CH_FETCH && lane < 32) {
         const bool have = e0 + lane < e1;
         n_idx[0][lane] = have ? sb.ev_node[e0 + lane] : LL_MAX;
         n_a[0][lane] = have ? sb.ev_agent[e0 + lane] : 0; n_type[0][lane] = have ? sb.ev_type[e0 + lane] : 0;
@@ -481,8 +484,8 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
             Gp->n_cls = n_cls;
         }
         for (int t = lane; t < nb; t += QS_WAVE) sb.acl_cnt[bot0 + t] = s_acnt[t] - sb.agent_ev[bot0 + t];
-    } else if (wave == CH_WAVES - 1) {
-        // =================================== the last wave: event fetch ===================================
+    } else if (wave == CH_FETCH) {
+        // =================================== wave CH_FETCH: event fetch ===================================
         for (;;) {
             const bool active = e < e1;
             if (!active && !have_prev) break;
