@@ -51,6 +51,7 @@ struct EsWs {
     unsigned int chunk;          //         filter steps per chunk of this launch
     unsigned int *chunk_base;    // [257]   exclusive prefix of ceil(count / chunk)
     unsigned int *idx;           // [n]     packet index of every accepted record, bot-major
+    unsigned int *tile_off;      // [257][n_tiles] records of a bot in a tile of ES_TILE packets -> where they start in idx
     EsRec *rec;                  // [n]
     unsigned long long *cmax;    // [chunks] max t over the chunk's init / step records (ordered key), 0 = none
     double *last_in;             // [chunks] filter's last predict time at chunk start
@@ -81,20 +82,32 @@ __device__ inline void es_sincos(double x, double *sn, double *cs)
     *cs = (q == 0) ? c : (q == 1) ? -s : (q == 2) ? -c : s;
 }
 
-// ---- index: accepted records per bot, bot-major order ---------------------------------------------
-__global__ void __launch_bounds__(256)
-es_count_kernel(size_t n, QsBatch b, int max_agent, unsigned int *__restrict__ count)
+// ---- index: accepted records per bot, bot-major order (a stable partition by bot) ----------------
+// one workgroup per tile of ES_TILE packets: the tile's records per bot -> tile_cnt[bot][tile], and the
+// per-bot totals
+#define ES_TILE 16384
+#define ES_CMP_BLOCK 1024
+#define ES_CMP_PER (ES_TILE / ES_CMP_BLOCK)
+__global__ void __launch_bounds__(ES_CMP_BLOCK)
+es_count_kernel(size_t n, QsBatch b, int max_agent, EsWs ws, unsigned int n_tiles)
 {
     __shared__ unsigned int s_cnt[QS_MAX_AGENT + 1];
-    for (int a = threadIdx.x; a <= QS_MAX_AGENT; a += 256) s_cnt[a] = 0;
+    for (int a = threadIdx.x; a <= QS_MAX_AGENT; a += ES_CMP_BLOCK) s_cnt[a] = 0;
     __syncthreads();
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const int a = b.agent[i];
-        if (b.accept[i] && a >= 1 && a <= max_agent) atomicAdd(&s_cnt[a], 1u);
+    const size_t i0 = (size_t)blockIdx.x * ES_TILE;
+    for (int k = 0; k < ES_CMP_PER; k++) {
+        const size_t i = i0 + (size_t)k * ES_CMP_BLOCK + threadIdx.x;
+        if (i < n) {
+            const int a = b.agent[i];
+            if (b.accept[i] && a >= 1 && a <= max_agent) atomicAdd(&s_cnt[a], 1u);
+        }
     }
     __syncthreads();
-    for (int a = threadIdx.x; a <= QS_MAX_AGENT; a += 256)
-        if (s_cnt[a]) atomicAdd(&count[a], s_cnt[a]);
+    for (int a = threadIdx.x; a <= QS_MAX_AGENT; a += ES_CMP_BLOCK) {
+        const unsigned int v = s_cnt[a];
+        ws.tile_off[(size_t)a * n_tiles + blockIdx.x] = v;
+        if (v) atomicAdd(&ws.count[a], v);
+    }
 }
 
 __global__ void __launch_bounds__(256)
@@ -117,45 +130,54 @@ es_plan_kernel(EsWs ws, int max_agent)
     if (a == 255) { ws.base[256] = s_a[255]; ws.chunk_base[256] = s_c[255]; }
 }
 
-// one workgroup per bot: stable compaction of the bot's accepted packet indices
-#define ES_CMP_BLOCK 1024
-#define ES_CMP_PER 16
+// one wave per bot: where each tile's records of the bot start (its base + the tiles before)
+__global__ void __launch_bounds__(QS_WAVE)
+es_tile_scan_kernel(EsWs ws, unsigned int n_tiles)
+{
+    const int bot = blockIdx.x + 1, lane = threadIdx.x;
+    unsigned int run = ws.base[bot];
+    unsigned int *row = ws.tile_off + (size_t)bot * n_tiles;
+    for (unsigned int t0 = 0; t0 < n_tiles; t0 += QS_WAVE) {
+        const unsigned int t = t0 + lane;
+        const unsigned int v = t < n_tiles ? row[t] : 0u;
+        unsigned int inc = v;
+        #pragma unroll
+        for (int off = 1; off < QS_WAVE; off <<= 1) { const unsigned int u = __shfl_up(inc, off); if (lane >= off) inc += u; }
+        if (t < n_tiles) row[t] = run + inc - v;
+        run += __shfl(inc, QS_WAVE - 1);
+    }
+}
+
+// one workgroup per (tile, bot): stable compaction of the bot's accepted packet indices of that tile
 __global__ void __launch_bounds__(ES_CMP_BLOCK)
-es_compact_kernel(size_t n, QsBatch b, EsWs ws)
+es_compact_kernel(size_t n, QsBatch b, EsWs ws, unsigned int n_tiles)
 {
     __shared__ unsigned int s_wave[ES_CMP_BLOCK / QS_WAVE];
-    __shared__ unsigned int s_total;
-    const int bot = blockIdx.x + 1;
-    if (ws.count[bot] == 0) return;
+    const int bot = blockIdx.y + 1;
+    const unsigned int tile = blockIdx.x;
+    const unsigned int base = ws.tile_off[(size_t)bot * n_tiles + tile];
+    const unsigned int next = tile + 1 < n_tiles ? ws.tile_off[(size_t)bot * n_tiles + tile + 1] : ws.base[bot + 1];
+    if (next == base) return;                                  // none of the bot's records in this tile (uniform)
     const int tid = threadIdx.x, lane = tid & (QS_WAVE - 1), wave = tid >> 6;
-    unsigned int run = ws.base[bot];
-    for (size_t tile = 0; tile < n; tile += (size_t)ES_CMP_BLOCK * ES_CMP_PER) {
-        const size_t i0 = tile + (size_t)tid * ES_CMP_PER;
-        unsigned int mask = 0;
-        #pragma unroll
-        for (int k = 0; k < ES_CMP_PER; k++) {
-            const size_t i = i0 + k;
-            if (i < n && b.accept[i] && b.agent[i] == bot) mask |= 1u << k;
-        }
-        const unsigned int cnt = (unsigned int)__builtin_popcount(mask);
-        unsigned int inc = cnt;
-        #pragma unroll
-        for (int off = 1; off < QS_WAVE; off <<= 1) { const unsigned int v = __shfl_up(inc, off); if (lane >= off) inc += v; }
-        if (lane == QS_WAVE - 1) s_wave[wave] = inc;
-        __syncthreads();
-        if (tid == 0) {
-            unsigned int acc = 0;
-            for (int w = 0; w < ES_CMP_BLOCK / QS_WAVE; w++) { const unsigned int v = s_wave[w]; s_wave[w] = acc; acc += v; }
-            s_total = acc;
-        }
-        __syncthreads();
-        unsigned int pos = run + s_wave[wave] + inc - cnt;
-        #pragma unroll
-        for (int k = 0; k < ES_CMP_PER; k++)
-            if (mask & (1u << k)) ws.idx[pos++] = (unsigned int)(i0 + k);
-        run += s_total;
-        __syncthreads();
+    const size_t i0 = (size_t)tile * ES_TILE + (size_t)tid * ES_CMP_PER;
+    unsigned int mask = 0;
+    #pragma unroll
+    for (int k = 0; k < ES_CMP_PER; k++) {
+        const size_t i = i0 + k;
+        if (i < n && b.accept[i] && b.agent[i] == bot) mask |= 1u << k;
     }
+    const unsigned int cnt = (unsigned int)__builtin_popcount(mask);
+    unsigned int inc = cnt;
+    #pragma unroll
+    for (int off = 1; off < QS_WAVE; off <<= 1) { const unsigned int v = __shfl_up(inc, off); if (lane >= off) inc += v; }
+    if (lane == QS_WAVE - 1) s_wave[wave] = inc;
+    __syncthreads();
+    unsigned int before = 0;
+    for (int w = 0; w < wave; w++) before += s_wave[w];
+    unsigned int pos = base + before + inc - cnt;
+    #pragma unroll
+    for (int k = 0; k < ES_CMP_PER; k++)
+        if (mask & (1u << k)) ws.idx[pos++] = (unsigned int)(i0 + k);
 }
 
 __device__ inline int es_bot_of(const unsigned int *__restrict__ prefix, unsigned int v)
@@ -760,6 +782,8 @@ es_fold_kernel(EsWs ws, QsBatch b, const double *__restrict__ recv_time, double 
 // ---- host side ------------------------------------------------------------------------------------
 static inline size_t es_align(size_t v) { return (v + 255) & ~(size_t)255; }
 
+static size_t es_tiles(size_t n) { return (n + 16384 - 1) / 16384 + 1; }
+
 static size_t es_max_chunks(const qs_ctx *c, size_t n) { return n / ES_CHUNK_MIN + (size_t)c->cfg.max_agent + 2; }
 
 static unsigned int es_chunk_for(const qs_ctx *c, size_t n)
@@ -774,7 +798,7 @@ static unsigned int es_chunk_for(const qs_ctx *c, size_t n)
 size_t qs_ekf_scan_workspace_bytes(const qs_ctx *c, size_t n)
 {
     const size_t ch = es_max_chunks(c, n);
-    return es_align(256 * 4) + 2 * es_align(257 * 4) + es_align(n * 4) + es_align(n * sizeof(EsRec)) + es_align(ch * 8) +
+    return es_align(256 * 4) + 2 * es_align(257 * 4) + es_align(n * 4) + es_align(257 * es_tiles(n) * 4) + es_align(n * sizeof(EsRec)) + es_align(ch * 8) +
            es_align(ch * 8) + es_align(ch * sizeof(EsAgg1)) + es_align(ch * sizeof(EsStart)) + es_align(ch * sizeof(EsAgg2)) +
            es_align(256 * 20 * 8);
 }
@@ -800,6 +824,7 @@ hipError_t qs_launch_ekf_scan(qs_ctx *c, size_t n, const double *d_time, hipStre
     ws.base = (unsigned int *)p; p += es_align(257 * 4);
     ws.chunk_base = (unsigned int *)p; p += es_align(257 * 4);
     ws.idx = (unsigned int *)p; p += es_align(cap * 4);
+    ws.tile_off = (unsigned int *)p; p += es_align(257 * es_tiles(cap) * 4);
     ws.rec = (EsRec *)p; p += es_align(cap * sizeof(EsRec));
     ws.last_in = (double *)p; p += es_align(ch * 8);
     ws.agg1 = (EsAgg1 *)p; p += es_align(ch * sizeof(EsAgg1));
@@ -811,11 +836,11 @@ hipError_t qs_launch_ekf_scan(qs_ctx *c, size_t n, const double *d_time, hipStre
     const int ma = c->cfg.max_agent;
     const double t0 = (double)c->next_seq;
     const unsigned int chunks = (unsigned int)(n / ws.chunk + (size_t)c->cfg.max_agent + 2);
-    unsigned int cnt_blocks = (unsigned int)((n + 255) / 256);
-    if (cnt_blocks > 1024) cnt_blocks = 1024;
-    hipLaunchKernelGGL(es_count_kernel, dim3(cnt_blocks), dim3(256), 0, st, n, c->b, ma, ws.count);
+    const unsigned int n_tiles = (unsigned int)((n + ES_TILE - 1) / ES_TILE);
+    hipLaunchKernelGGL(es_count_kernel, dim3(n_tiles), dim3(ES_CMP_BLOCK), 0, st, n, c->b, ma, ws, n_tiles);
     hipLaunchKernelGGL(es_plan_kernel, dim3(1), dim3(256), 0, st, ws, ma);
-    hipLaunchKernelGGL(es_compact_kernel, dim3(ma), dim3(ES_CMP_BLOCK), 0, st, n, c->b, ws);
+    hipLaunchKernelGGL(es_tile_scan_kernel, dim3(ma), dim3(QS_WAVE), 0, st, ws, n_tiles);
+    hipLaunchKernelGGL(es_compact_kernel, dim3(n_tiles, ma), dim3(ES_CMP_BLOCK), 0, st, n, c->b, ws, n_tiles);
     hipLaunchKernelGGL(es_wire_kernel, dim3((unsigned int)((n + 255) / 256)), dim3(256), 0, st, n, c->b, d_time, t0, ws,
                        c->d_ekf_prev, c->cfg.ekf_metres_per_tick);
     hipLaunchKernelGGL(es_last_kernel, dim3((ma + 63) / 64), dim3(64), 0, st, ws, c->d_ekf, c->d_ekf_prev, ma);
