@@ -159,24 +159,16 @@ static int reset_state(qs_ctx *c)
     HIPCHK(c, hipMemsetAsync(c->d_stamps, 0, c->cells * sizeof(unsigned int), c->stream));
     if (c->d_counts) HIPCHK(c, hipMemsetAsync(c->d_counts, 0, c->cells * sizeof(unsigned long long), c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_drift, 0, (size_t)nb * 2 * sizeof(double), c->stream));
-    std::vector<long long> lc(nb, -(long long)c->cfg.min_poses_between);        // :271
-    HIPCHK(c, hipMemcpyAsync(c->d_last_closure, lc.data(), nb * sizeof(long long), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, qs_launch_fill_zone_identity(c));
     HIPCHK(c, hipMemsetAsync(c->d_counters, 0, QS_CNT_N * sizeof(unsigned long long), c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_graph_batch, 0, (size_t)c->n_graphs * 2 * sizeof(unsigned long long), c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_ekf, 0, (size_t)nb * 44 * sizeof(double), c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_ekf_prev, 0, (size_t)nb * 4 * sizeof(double), c->stream));
     // the bucket index of every graph: only what the session used of it (directory entries, first nodes,
-    // pool nodes), found from the landmark log on the device -- before the counters are zeroed below
+    // pool nodes), found from the landmark log on the device; then the graphs' counters and the bots' last
+    // closure (:271).  All enqueued: a reset does not wait for the GPU.
     HIPCHK(c, qs_launch_slam_reset_index(c));
-    std::vector<QsGraphDev> upd(c->h_graphs);
-    for (int g = 0; g < c->n_graphs; g++) {
-        upd[g].n_nodes = upd[g].n_lms = upd[g].n_cls = 0;
-        upd[g].n_misc = 0; upd[g].nodes_used = (unsigned int)(1 + c->dir_entries);
-        c->lms_upper[g] = 0; c->cls_upper[g] = 0;
-    }
-    HIPCHK(c, hipMemcpyAsync(c->d_graphs, upd.data(), upd.size() * sizeof(QsGraphDev), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));   // lc / upd are host temporaries
+    for (int g = 0; g < c->n_graphs; g++) { c->lms_upper[g] = 0; c->cls_upper[g] = 0; }
     c->next_seq = 0; c->epoch_base = 0; c->last_n = 0; c->last_has_poses = false; c->n_rebases = 0;
     return QS_OK;
 }

@@ -764,11 +764,28 @@ qs_slam_reset_index_kernel(const QsGraphDev *__restrict__ graphs, QsBucketGeom b
     }
 }
 
+// ... and then the graphs' counters and the bots' last closure (:271), on the device: a reset is all
+// enqueued work, no host staging to wait for
+__global__ void __launch_bounds__(256)
+qs_slam_reset_counters_kernel(QsGraphDev *__restrict__ graphs, int n_graphs, unsigned int first_pool,
+                              long long *__restrict__ last_closure, int nb, long long lc_value)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < n_graphs) {
+        QsGraphDev *G = graphs + t;
+        G->n_nodes = 0; G->n_lms = 0; G->n_cls = 0; G->n_misc = 0; G->nodes_used = first_pool;
+    }
+    if (t < nb) last_closure[t] = lc_value;
+}
+
 hipError_t qs_launch_slam_reset_index(qs_ctx *c)
 {
     if (!c->d_graphs || c->n_graphs <= 0) return hipSuccess;
-    hipLaunchKernelGGL(qs_slam_reset_index_kernel, dim3(64, c->n_graphs), dim3(256), 0, c->stream, c->d_graphs, c->bg,
-                       (unsigned int)(1 + c->dir_entries));
+    const unsigned int first_pool = (unsigned int)(1 + c->dir_entries);
+    const int nb = c->cfg.max_agent + 1, m = nb > c->n_graphs ? nb : c->n_graphs;
+    hipLaunchKernelGGL(qs_slam_reset_index_kernel, dim3(64, c->n_graphs), dim3(256), 0, c->stream, c->d_graphs, c->bg, first_pool);
+    hipLaunchKernelGGL(qs_slam_reset_counters_kernel, dim3((m + 255) / 256), dim3(256), 0, c->stream, c->d_graphs, c->n_graphs,
+                       first_pool, c->d_last_closure, nb, -(long long)c->cfg.min_poses_between);
     return hipGetLastError();
 }
 
