@@ -70,7 +70,8 @@ const char *qs_last_error(const qs_ctx *ctx);   /* ctx may be NULL: last create 
 /* run on the caller's hipStream_t (e.g. torch's current stream); NULL = own stream */
 int qs_set_stream(qs_ctx *ctx, void *hip_stream);
 int qs_sync(qs_ctx *ctx);
-/* new session: grid -> UNKNOWN, pose graphs, drift, zones, EKF cleared (main() start, :755-785) */
+/* new session: grid -> UNKNOWN, pose graphs, drift, zones, EKF cleared (main() start, :755-785).
+ * Enqueued on the context's stream like an ingest; does not wait for the GPU. */
 int qs_reset(qs_ctx *ctx);
 /* per-bot x offset; bot 2 defaults to cfg.separation (:851-852) */
 int qs_set_bot_offset(qs_ctx *ctx, int32_t bot, double off_x);
