@@ -162,7 +162,7 @@ qs_slam_index_kernel(size_t n, QsBatch b, QsSlamBatch sb, const QsGraphDev *__re
 #define CH_FETCH (CH_WAVES - 2)     // the wave that fetches the events
 #define CH_AGW (CH_WAVES - 3)       // query waves 1 .. CH_AGW: agent a belongs to wave 1 + a % CH_AGW
 
-// barrier that orders LDS traffic only (the two intra-window hand-offs go through LDS; a full
+// barrier that orders LDS traffic only (the hand-offs between the roles go through LDS; a full
 // __syncthreads would also wait for every outstanding global store to be acknowledged)
 __device__ inline void lds_barrier()
 {
@@ -171,13 +171,13 @@ __device__ inline void lds_barrier()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-// Bucket index along one axis.  Only consistency between insert and query matters (not the
+// Bucket cell along one axis.  Only consistency between insert and query matters (not the
 // reference's arithmetic): the edge exceeds the closure radius by 1e-9 relative, so two points
-// closer than the radius are never two buckets apart whatever the rounding of this product.
+// closer than the radius are never two cells apart whatever the rounding of this product.
 __device__ inline int bucket_coord(double v, double b0, double inv_cell)
 {
     const double f = floor((v - b0) * inv_cell);
-    // one conversion instruction (f64 -> i64 is a sequence); monotone, so that clamping to the grid is too
+    // one conversion instruction (f64 -> i64 is a sequence); monotone, saturating at +-1e9 cells
     return (fabs(f) < 1.0e9) ? (int)f : (f > 0 ? 1000000000 : -1000000000);
 }
 
