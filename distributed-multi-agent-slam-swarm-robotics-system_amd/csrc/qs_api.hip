@@ -409,6 +409,31 @@ static int reserve_graphs_for_batch(qs_ctx *c, size_t n)
         for (int g = 0; g < c->n_graphs; g++) { c->lms_upper[g] += (long long)n; c->cls_upper[g] += (long long)n; }
         return QS_OK;
     }
+    // The batch's landmark events per graph are known on the device only.  Asking costs a host sync in the
+    // middle of the pipeline (every launch after the decode waits for it), so when memory allows, the graphs
+    // that are short are simply grown to the safe bound -- every record a landmark of that graph -- and the
+    // next batches of this size go through without a question: ~260 B per unit of capacity (log, closures,
+    // side list, worst-case node pool), against 288 GB.
+    {
+        const double unit = 2 * 8 + 8 + 1 + 2 * 8 + 2 * 8 + 4 + sizeof(QsLmNode) + 4;
+        double extra = 0;
+        for (int g = 0; g < c->n_graphs; g++) {
+            const long long nl = c->lms_upper[g] + (long long)n, nc = c->cls_upper[g] + (long long)n;
+            if (nl > c->h_graphs[g].cap_lms) extra += (double)(2 * nl - c->h_graphs[g].cap_lms) * unit;     // (capacities double)
+            if (!c->h_graphs[g].nodes) extra += (double)(1 + c->dir_entries) * (sizeof(QsLmNode) + 4 + sizeof(QsDirEntry));   // first nodes
+            if (nc > c->h_graphs[g].cap_cls) extra += (double)(2 * nc - c->h_graphs[g].cap_cls) * 32.0;
+        }
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && extra <= 0.25 * (double)free_b) {
+            for (int g = 0; g < c->n_graphs; g++) {
+                const long long nl = c->lms_upper[g] + (long long)n, nc = c->cls_upper[g] + (long long)n;
+                int rc = graph_reserve(c, g, nl, nc, c->lms_upper[g], c->cls_upper[g]);
+                if (rc != QS_OK) return rc;
+                c->lms_upper[g] = nl; c->cls_upper[g] = nc;
+            }
+            return QS_OK;
+        }
+    }
     // tighten the bounds with the exact device-side numbers, then grow what is really short
     std::vector<QsGraphDev> cur(c->n_graphs);
     std::vector<unsigned long long> gb((size_t)c->n_graphs * 2);
