@@ -6,6 +6,8 @@
 
 #define DEC_BLOCK 256
 #define DEC_MAX_STRIDE 64   // records are staged through LDS when stride <= 64 bytes
+#define DEC_TILES 8         // tiles of DEC_BLOCK records per workgroup: the per-graph / per-bot counts reach HBM once per
+                            // workgroup (64 bots: half a million same-address atomics per 2^20 packets otherwise)
 
 // One workgroup stages DEC_BLOCK consecutive records (DEC_BLOCK*stride contiguous bytes) into
 // LDS with coalesced dword loads, then each lane parses its own record from LDS: the 42-byte
@@ -21,14 +23,19 @@ qs_decode_kernel(const unsigned char *__restrict__ pkts, size_t n, size_t stride
     __shared__ unsigned int s_raw[DEC_BLOCK * DEC_MAX_STRIDE / 4 + 2];
     __shared__ unsigned int s_agent_ev[QS_MAX_AGENT + 1];
     __shared__ unsigned int s_acc, s_hist_small[64][2];
-    const size_t base = (size_t)blockIdx.x * DEC_BLOCK;
+    const size_t block_base = (size_t)blockIdx.x * DEC_BLOCK * DEC_TILES;
     const int tid = threadIdx.x;
-    const size_t nrec = (n - base < DEC_BLOCK) ? (n - base) : DEC_BLOCK;
     const bool small_g = n_graphs <= 64;
 
     if (tid == 0) s_acc = 0;
     if (small_g && tid < 64) { s_hist_small[tid][0] = 0; s_hist_small[tid][1] = 0; }
     for (int t = tid; t <= QS_MAX_AGENT; t += DEC_BLOCK) s_agent_ev[t] = 0;
+
+  for (int tile = 0; tile < DEC_TILES; tile++) {
+    const size_t base = block_base + (size_t)tile * DEC_BLOCK;
+    if (base >= n) break;                                       // (uniform)
+    const size_t nrec = (n - base < DEC_BLOCK) ? (n - base) : DEC_BLOCK;
+    if (tile) __syncthreads();                                  // the previous tile is parsed: its bytes may go
 
     // stage: the byte range [base*stride, (base+nrec)*stride) widened to dword boundaries
     const size_t byte0 = base * stride;
@@ -102,6 +109,7 @@ qs_decode_kernel(const unsigned char *__restrict__ pkts, size_t n, size_t stride
         atomicAdd(&s_acc, 1u);
         if (lmk) atomicAdd(&s_agent_ev[agent], 1u);
     }
+  }
     __syncthreads();
     for (int t = tid; t <= max_agent; t += DEC_BLOCK)
         if (s_agent_ev[t]) atomicAdd(&agent_ev[t], s_agent_ev[t]);
@@ -110,7 +118,8 @@ qs_decode_kernel(const unsigned char *__restrict__ pkts, size_t n, size_t stride
         if (s_hist_small[tid][1]) atomicAdd(&graph_batch[2 * tid + 1], (unsigned long long)s_hist_small[tid][1]);
     }
     if (tid == 0) {
-        atomicAdd(&counters[QS_CNT_DATAGRAMS], (unsigned long long)nrec);
+        const size_t left = n - block_base;
+        atomicAdd(&counters[QS_CNT_DATAGRAMS], (unsigned long long)(left < (size_t)DEC_BLOCK * DEC_TILES ? left : (size_t)DEC_BLOCK * DEC_TILES));
         if (s_acc) atomicAdd(&counters[QS_CNT_ACCEPTED], (unsigned long long)s_acc);
     }
 }
@@ -160,7 +169,7 @@ hipError_t qs_launch_decode(qs_ctx *c, const unsigned char *d_pkts, size_t n, si
     if (n == 0) return hipSuccess;
     const unsigned int blocks = (unsigned int)((n + DEC_BLOCK - 1) / DEC_BLOCK);
     if (stride <= DEC_MAX_STRIDE)
-        hipLaunchKernelGGL(qs_decode_kernel, dim3(blocks), dim3(DEC_BLOCK), 0, c->stream, d_pkts, n,
+        hipLaunchKernelGGL(qs_decode_kernel, dim3((blocks + DEC_TILES - 1) / DEC_TILES), dim3(DEC_BLOCK), 0, c->stream, d_pkts, n,
                            stride, d_lens, c->d_offset, c->cfg.max_agent, c->bots_per_graph,
                            c->n_graphs, c->b, c->d_graph_batch, c->sb.agent_ev, c->d_counters);
     else
