@@ -42,7 +42,9 @@ def parse():
     ap.add_argument("--no-counts", action="store_true", help="tri-state stamps only (no hit/miss counters)")
     ap.add_argument("--ekf", type=int, default=1, help="run the per-bot EKF stage (1) or not (0)")
     ap.add_argument("--bots", type=int, default=2, help="bots per GPU (2 = configs[1], the judged workload; 64 = configs[2] shape)")
-    ap.add_argument("--bots-per-graph", type=int, default=0, help="bots sharing one pose graph (0 = all)")
+    ap.add_argument("--bots-per-graph", type=int, default=-1,
+                    help="bots sharing one pose graph: -1 = the reference's deployment unit (2 bots per mapper process, i.e. "
+                         "per pose graph), 0 = all bots of the GPU in one graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0,
                     help="packets of the same stream timed on the CPU (0: one whole step; the reference's closure\n"
@@ -113,6 +115,8 @@ def measured_copy_gbs(torch, dev):
 
 def main():
     args = parse()
+    if args.bots_per_graph < 0:
+        args.bots_per_graph = 2 if args.bots > 2 else 0
     import torch
     import torch.distributed as dist
 
