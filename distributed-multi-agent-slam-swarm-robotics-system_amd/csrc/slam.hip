@@ -231,39 +231,47 @@ __device__ inline void chain_insert_lanes(const QsGraphDev &G, bool inw, int ran
     }
     QsDirEntry de = {0, 0, 0, 0};
     if (inb) de = G.dir[kb];
+    // the events of one bucket: position among them (lane = node order), how many, who goes first -- the only
+    // part that walks the distinct buckets one by one; everything after is lane-parallel
+    unsigned int grank = 0, gsize = 0;
+    int ldr = lane;
     for (unsigned long long rem = __ballot(inb); rem;) {
         const int ld = __ffsll((long long)rem) - 1;
         const long long kk = rl64(key, ld);
         const unsigned long long grp = __ballot(inb && key == kk);
-        const int gsize = __popcll(grp);
-        // an empty bucket's tail is its first node, the one that belongs to the directory entry
-        const unsigned int head = __builtin_amdgcn_readlane(de.head, ld);
-        const unsigned int tail = head ? __builtin_amdgcn_readlane(de.tail, ld) : 1u + (unsigned int)kk;
-        const unsigned int tc = head ? __builtin_amdgcn_readlane(de.tail_cnt, ld) : 0u;
-        const unsigned int total = tc + gsize;
-        const unsigned int nn = total > QS_NODE_CAP ? (total - QS_NODE_CAP + QS_NODE_CAP - 1) / QS_NODE_CAP : 0;
-        const unsigned int base = pool;
-        if (inb && key == kk && (long long)base + nn <= G.node_cap) {
-            const unsigned int p = tc + __popcll(grp & ((1ull << lane) - 1));
-            const unsigned int nd = p < QS_NODE_CAP ? tail : base + (p - QS_NODE_CAP) / QS_NODE_CAP;
-            const unsigned int sl = p < QS_NODE_CAP ? p : (p - QS_NODE_CAP) % QS_NODE_CAP;
-            QsLmNode *np = G.nodes + nd;
-            np->idx[sl] = idx; np->x[sl] = x; np->y[sl] = y;
-            if (lane == ld) {
-                QsDirEntry upd;
-                upd.head = 1u + (unsigned int)kk; upd.tail = tail; upd.tail_cnt = total; upd.pad = 0;
-                if (nn) {
-                    for (unsigned int q = 0; q + 1 < nn; q++) G.nd_next[base + q] = base + q + 1;
-                    G.nd_next[tail] = base;
-                    upd.tail = base + nn - 1;
-                    upd.tail_cnt = total - QS_NODE_CAP * nn;
-                }
-                G.dir[kk] = upd;
-            }
-        }
-        pool += nn;
+        if (inb && key == kk) { grank = (unsigned int)__popcll(grp & ((1ull << lane) - 1)); gsize = (unsigned int)__popcll(grp); ldr = ld; }
         rem &= ~grp;
     }
+    // an empty bucket's tail is its first node, the one that belongs to the directory entry
+    const unsigned int tail = de.head ? de.tail : 1u + (unsigned int)key;
+    const unsigned int tc = de.head ? de.tail_cnt : 0u;
+    const unsigned int total = tc + gsize;
+    const unsigned int nn = (inb && total > QS_NODE_CAP) ? (total - QS_NODE_CAP + QS_NODE_CAP - 1) / QS_NODE_CAP : 0;   // new pool nodes
+    // pool nodes are handed out bucket by bucket, in the order of the buckets' first events
+    const unsigned int mine = (inb && ldr == lane) ? nn : 0u;
+    unsigned int incl = mine;
+    #pragma unroll
+    for (int off = 1; off < QS_WAVE; off <<= 1) { const unsigned int v = __shfl_up(incl, off); if (lane >= off) incl += v; }
+    const unsigned int base = __shfl(pool + incl - mine, ldr);
+    if (inb && (long long)base + nn <= G.node_cap) {
+        const unsigned int p = tc + grank;
+        const unsigned int nd = p < QS_NODE_CAP ? tail : base + (p - QS_NODE_CAP) / QS_NODE_CAP;
+        const unsigned int sl = p < QS_NODE_CAP ? p : (p - QS_NODE_CAP) % QS_NODE_CAP;
+        QsLmNode *np = G.nodes + nd;
+        np->idx[sl] = idx; np->x[sl] = x; np->y[sl] = y;
+        if (ldr == lane) {
+            QsDirEntry upd;
+            upd.head = 1u + (unsigned int)key; upd.tail = tail; upd.tail_cnt = total; upd.pad = 0;
+            if (nn) {
+                for (unsigned int q = 0; q + 1 < nn; q++) G.nd_next[base + q] = base + q + 1;
+                G.nd_next[tail] = base;
+                upd.tail = base + nn - 1;
+                upd.tail_cnt = total - QS_NODE_CAP * nn;
+            }
+            G.dir[key] = upd;
+        }
+    }
+    pool += __shfl(incl, QS_WAVE - 1);
     n_lms += k;
 }
 
