@@ -210,27 +210,41 @@ __device__ inline long long bucket_key(int type, int cx, int cy, const QsBucketG
 }
 
 
+// The graph's pointers come out of a struct in memory, so the compiler has to treat them as FLAT
+// (could be LDS): a flat load counts on the LDS counter too, and every wait for an LDS read would
+// also wait for the node rows in flight.  The query waves read the index through global pointers.
+#define QS_GLOBAL __attribute__((address_space(1)))
+typedef const QS_GLOBAL QsLmNode *QsNodeG;
+typedef const QS_GLOBAL unsigned int *QsU32G;
+
 // Landmark log and bucket index: `k` events of one graph, in node order, one per lane (`inw` lanes, rank =
 // the lane's position among them).  Appends to the reference's insertion-ordered log and to the bucket
 // chains; events of one bucket are appended in lane (= node) order.
 __device__ inline void chain_insert_lanes(const QsGraphDev &G, bool inw, int rank, long long idx, long long kb, double x, double y,
                                           int type, int k, int lane, long long &n_lms, long long &n_misc, unsigned int &pool)
 {
+    // (global address space: the graph's pointers come out of a struct in memory and would be FLAT otherwise)
+    QS_GLOBAL double *const lm_x = (QS_GLOBAL double *)G.lm_x, *const lm_y = (QS_GLOBAL double *)G.lm_y;
+    QS_GLOBAL long long *const lm_idx = (QS_GLOBAL long long *)G.lm_idx;
+    QS_GLOBAL unsigned char *const lm_type = (QS_GLOBAL unsigned char *)G.lm_type;
+    QS_GLOBAL unsigned int *const misc = (QS_GLOBAL unsigned int *)G.misc, *const nd_next = (QS_GLOBAL unsigned int *)G.nd_next;
+    QS_GLOBAL QsDirEntry *const dir = (QS_GLOBAL QsDirEntry *)G.dir;
+    QS_GLOBAL QsLmNode *const nodes = (QS_GLOBAL QsLmNode *)G.nodes;
     // self.landmarks.append((x, y, landmark_type, idx))  :288
     const long long log_slot = n_lms + rank;
     if (inw && log_slot < G.cap_lms) {
-        G.lm_x[log_slot] = x; G.lm_y[log_slot] = y; G.lm_idx[log_slot] = idx; G.lm_type[log_slot] = (unsigned char)type;
+        lm_x[log_slot] = x; lm_y[log_slot] = y; lm_idx[log_slot] = idx; lm_type[log_slot] = (unsigned char)type;
     }
     const bool inb = inw && kb >= 0;                              // the centre bucket exists
     const long long key = inb ? kb : -1;
     const bool is_misc = inw && !inb;
     {
         const unsigned long long mm = __ballot(is_misc);
-        if (is_misc && log_slot < G.cap_lms) G.misc[n_misc + __popcll(mm & ((1ull << lane) - 1))] = (unsigned int)log_slot;
+        if (is_misc && log_slot < G.cap_lms) misc[n_misc + __popcll(mm & ((1ull << lane) - 1))] = (unsigned int)log_slot;
         n_misc += __popcll(mm);
     }
     QsDirEntry de = {0, 0, 0, 0};
-    if (inb) de = G.dir[kb];
+    if (inb) { de.head = dir[kb].head; de.tail = dir[kb].tail; de.tail_cnt = dir[kb].tail_cnt; }
     // the events of one bucket: position among them (lane = node order), how many, who goes first -- the only
     // part that walks the distinct buckets one by one; everything after is lane-parallel
     unsigned int grank = 0, gsize = 0;
@@ -257,18 +271,18 @@ __device__ inline void chain_insert_lanes(const QsGraphDev &G, bool inw, int ran
         const unsigned int p = tc + grank;
         const unsigned int nd = p < QS_NODE_CAP ? tail : base + (p - QS_NODE_CAP) / QS_NODE_CAP;
         const unsigned int sl = p < QS_NODE_CAP ? p : (p - QS_NODE_CAP) % QS_NODE_CAP;
-        QsLmNode *np = G.nodes + nd;
+        QS_GLOBAL QsLmNode *np = nodes + nd;
         np->idx[sl] = idx; np->x[sl] = x; np->y[sl] = y;
         if (ldr == lane) {
             QsDirEntry upd;
             upd.head = 1u + (unsigned int)key; upd.tail = tail; upd.tail_cnt = total; upd.pad = 0;
             if (nn) {
-                for (unsigned int q = 0; q + 1 < nn; q++) G.nd_next[base + q] = base + q + 1;
-                G.nd_next[tail] = base;
+                for (unsigned int q = 0; q + 1 < nn; q++) nd_next[base + q] = base + q + 1;
+                nd_next[tail] = base;
                 upd.tail = base + nn - 1;
                 upd.tail_cnt = total - QS_NODE_CAP * nn;
             }
-            G.dir[key] = upd;
+            dir[key].head = upd.head; dir[key].tail = upd.tail; dir[key].tail_cnt = upd.tail_cnt; dir[key].pad = 0;
         }
     }
     pool += __shfl(incl, QS_WAVE - 1);
@@ -290,13 +304,6 @@ __device__ inline void chain_insert_window(const QsGraphDev &G, const QsBucketGe
     const long long kb = bucket_cell(x, y, type, bg, cx, cy) ? bucket_key(type, cx, cy, bg) : -1;   // -1: side list
     chain_insert_lanes(G, lane < k, lane, idx, kb, x, y, type, k, lane, n_lms, n_misc, pool);
 }
-
-// The graph's pointers come out of a struct in memory, so the compiler has to treat them as FLAT
-// (could be LDS): a flat load counts on the LDS counter too, and every wait for an LDS read would
-// also wait for the node rows in flight.  The query waves read the index through global pointers.
-#define QS_GLOBAL __attribute__((address_space(1)))
-typedef const QS_GLOBAL QsLmNode *QsNodeG;
-typedef const QS_GLOBAL unsigned int *QsU32G;
 
 // wave-uniform read of one lane of a double
 __device__ inline double rlf64(double v, int src_lane) { return __longlong_as_double(rl64(__double_as_longlong(v), src_lane)); }
