@@ -15,7 +15,7 @@ HEADER = os.path.join(os.path.dirname(_HERE), "include", "quasar_slam.h")
 QS_CNT_NAMES = ("datagrams", "accepted", "rays", "cells", "hits", "closures", "landmarks", "rebases",
                 "slam_windows", "slam_rounds", "slam_node_iters", "slam_misc_iters", "slam_cycles",
                 "slam_realtime_100mhz", "slam_cyc_prepare", "slam_cyc_query", "slam_cyc_commit", "ekf_wrap_clamp")
-QS_STAGE_NAMES = ("decode", "slam", "raycast", "ekf")
+QS_STAGE_NAMES = ("decode", "slam", "raycast", "ekf", "slam_chain", "rc_rays", "rc_sort", "rc_raster")
 UINT64_MAX = (1 << 64) - 1
 
 
@@ -37,7 +37,9 @@ class QsConfig(C.Structure):
         ("device", C.c_int32),
         ("raycast_mode", C.c_int32),
         ("seq_stride", C.c_int32),
-        ("reserved", C.c_int32 * 6),
+        ("shard_bots", C.c_int32),
+        ("shard_rank", C.c_int32),
+        ("reserved", C.c_int32 * 4),
     ]
 
 
@@ -92,6 +94,11 @@ SIGNATURES = {
     "qs_zone_packet": (_i32, [_vp, _i32, _i32, _vp]),
     "qs_fuse": (_i32, [_vp, C.POINTER(_vp), _sz]),
     "qs_fuse_buffers": (_i32, [_vp, C.POINTER(_vp), C.POINTER(_vp), _sz]),
+    "qs_fuse_buffers_range": (_i32, [_vp, C.POINTER(_vp), C.POINTER(_vp), _sz, _sz, _sz, _i32]),
+    "qs_fused_counts": (_i32, [_vp, C.POINTER(_vp), C.POINTER(_sz)]),
+    "qs_counts_source": (_i32, [_vp, _i32]),
+    "qs_epoch_query": (_i32, [_vp, _u64, _sz, C.POINTER(_i32)]),
+    "qs_mark_fused": (_i32, [_vp]),
     "qs_grid_to_pcd": (_i32, [_vp, _vp, _i32, _i32, _f64, _f64, _f64, _vp, _sz, C.POINTER(_sz)]),
     "qs_rasterise": (_i32, [_vp, _vp, _sz, _f64, _vp, _vp, _vp]),
     "qs_icp": (_i32, [_vp, _vp, _sz, _vp, _sz, _f64, _i32, _f64, _f64, _vp, _vp, _vp, _vp]),

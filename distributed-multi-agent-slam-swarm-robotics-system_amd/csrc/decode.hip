@@ -95,6 +95,7 @@ qs_decode_kernel(const unsigned char *__restrict__ pkts, size_t n, size_t stride
             }
         }
         b.accept[i] = ok ? 1 : 0;
+        if (b.map_ok != b.accept) b.map_ok[i] = (ok && agent >= b.own_lo && agent <= b.own_hi) ? 1 : 0;
     }
     // per-graph accepted / landmark-event counts of the batch (capacity planning + counters)
     if (ok) {
@@ -160,6 +161,7 @@ qs_decode_wide_kernel(const unsigned char *__restrict__ pkts, size_t n, size_t s
         }
     }
     b.accept[i] = ok ? 1 : 0;
+    if (b.map_ok != b.accept) b.map_ok[i] = (ok && r[4] >= b.own_lo && r[4] <= b.own_hi) ? 1 : 0;
     atomicAdd(&counters[QS_CNT_DATAGRAMS], 1ull);
 }
 

@@ -210,7 +210,7 @@ qs_ekf_ingest_kernel(size_t n, QsBatch b, const double *__restrict__ recv_time, 
     #pragma unroll
     for (int q = 0; q < EKF_GROUP; q++) {
         const size_t i = (size_t)q * QS_WAVE + lane;
-        acc_n[q] = i < n ? b.accept[i] : 0; ag_n[q] = i < n ? b.agent[i] : 0;
+        acc_n[q] = i < n ? b.map_ok[i] : 0; ag_n[q] = i < n ? b.agent[i] : 0;
     }
     for (size_t gbase = 0; gbase < n; gbase += EKF_GROUP * QS_WAVE) {
         unsigned char acc_c[EKF_GROUP], ag_c[EKF_GROUP];
@@ -219,7 +219,7 @@ qs_ekf_ingest_kernel(size_t n, QsBatch b, const double *__restrict__ recv_time, 
         #pragma unroll
         for (int q = 0; q < EKF_GROUP; q++) {
             const size_t i = gbase + (size_t)(EKF_GROUP + q) * QS_WAVE + lane;
-            acc_n[q] = i < n ? b.accept[i] : 0; ag_n[q] = i < n ? b.agent[i] : 0;
+            acc_n[q] = i < n ? b.map_ok[i] : 0; ag_n[q] = i < n ? b.agent[i] : 0;
         }
       #pragma unroll
       for (int sub = 0; sub < EKF_GROUP; sub++) {

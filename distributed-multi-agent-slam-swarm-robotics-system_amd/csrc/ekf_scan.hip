@@ -99,7 +99,7 @@ es_count_kernel(size_t n, QsBatch b, int max_agent, EsWs ws, unsigned int n_tile
         const size_t i = i0 + (size_t)k * ES_CMP_BLOCK + threadIdx.x;
         if (i < n) {
             const int a = b.agent[i];
-            if (b.accept[i] && a >= 1 && a <= max_agent) atomicAdd(&s_cnt[a], 1u);
+            if (b.map_ok[i] && a >= 1 && a <= max_agent) atomicAdd(&s_cnt[a], 1u);
         }
     }
     __syncthreads();
@@ -164,7 +164,7 @@ es_compact_kernel(size_t n, QsBatch b, EsWs ws, unsigned int n_tiles)
     #pragma unroll
     for (int k = 0; k < ES_CMP_PER; k++) {
         const size_t i = i0 + k;
-        if (i < n && b.accept[i] && b.agent[i] == bot) mask |= 1u << k;
+        if (i < n && b.map_ok[i] && b.agent[i] == bot) mask |= 1u << k;
     }
     const unsigned int cnt = (unsigned int)__builtin_popcount(mask);
     unsigned int inc = cnt;

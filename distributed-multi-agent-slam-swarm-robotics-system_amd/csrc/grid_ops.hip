@@ -64,8 +64,8 @@ qs_logodds_kernel(const unsigned long long *__restrict__ counts, size_t cells, f
 }
 hipError_t qs_launch_logodds(qs_ctx *c, float l_occ, float l_free, float lmin, float lmax, float *out_dev)
 {
-    hipLaunchKernelGGL(qs_logodds_kernel, dim3(go_blocks(c->cells)), dim3(GO_BLOCK), 0, c->stream, c->d_counts,
-                       c->cells, l_occ, l_free, lmin, lmax, out_dev);
+    hipLaunchKernelGGL(qs_logodds_kernel, dim3(go_blocks(c->cells)), dim3(GO_BLOCK), 0, c->stream,
+                       c->counts_view_fused ? c->d_counts_fused : c->d_counts, c->cells, l_occ, l_free, lmin, lmax, out_dev);
     return hipGetLastError();
 }
 
@@ -83,7 +83,7 @@ qs_split_counts_kernel(const unsigned long long *__restrict__ counts, size_t cel
 hipError_t qs_launch_split_counts(qs_ctx *c, int *hits_dev, int *misses_dev)
 {
     hipLaunchKernelGGL(qs_split_counts_kernel, dim3(go_blocks(c->cells)), dim3(GO_BLOCK), 0, c->stream,
-                       c->d_counts, c->cells, hits_dev, misses_dev);
+                       c->counts_view_fused ? c->d_counts_fused : c->d_counts, c->cells, hits_dev, misses_dev);
     return hipGetLastError();
 }
 
@@ -110,53 +110,83 @@ hipError_t qs_launch_rebase(qs_ctx *c)
 // ---- K3: grid fuse.  Both bots write one shared grid in the reference (dual_bot_mapper.py:785,
 // :851-852); with per-context / per-GPU grids the same result is the cell-wise latest stamp
 // (max) and the sum of the counters.  One pass: (n_src + 1) reads + 1 write per cell.
+// A thread keeps FUSE_UNROLL source loads (16 B each) in flight before it folds them: the sources are
+// independent streams, and a dependent load-fold-load chain per source left the HBM queues a source deep.
+// Sources are read once (non-temporal); the destination stays in the cache hierarchy for the views.
 #define FUSE_MAX_SRC 64
+#define FUSE_UNROLL 8
 struct FuseSrcs { const uint4 *s[FUSE_MAX_SRC]; };
 struct FuseCnts { const ulonglong2 *s[FUSE_MAX_SRC]; };
 
+__device__ inline uint4 go_ld_nt(const uint4 *p)
+{
+    typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+    const v4u v = __builtin_nontemporal_load((const v4u *)p);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ inline ulonglong2 go_ld_nt(const ulonglong2 *p)
+{
+    typedef unsigned long long v2u __attribute__((ext_vector_type(2)));
+    const v2u v = __builtin_nontemporal_load((const v2u *)p);
+    return make_ulonglong2(v.x, v.y);
+}
+__device__ inline void go_fold(uint4 &v, const uint4 u)
+{
+    v.x = u.x > v.x ? u.x : v.x; v.y = u.y > v.y ? u.y : v.y;
+    v.z = u.z > v.z ? u.z : v.z; v.w = u.w > v.w ? u.w : v.w;
+}
+__device__ inline void go_fold(ulonglong2 &v, const ulonglong2 u)
+{
+    v.x += u.x; v.y += u.y;      // hi32/lo32 halves add independently (no carry below 2^32 writes)
+}
+
+template <typename V, typename S>
 __global__ void __launch_bounds__(GO_BLOCK)
-qs_fuse_stamps_kernel(uint4 *__restrict__ dst, FuseSrcs src, int n_src, size_t n4)
+qs_fuse_kernel(V *__restrict__ dst, S src, int n_src, size_t nv)
 {
     const size_t stride = (size_t)gridDim.x * GO_BLOCK;
-    for (size_t k = (size_t)blockIdx.x * GO_BLOCK + threadIdx.x; k < n4; k += stride) {
-        uint4 v = dst[k];
-        for (int q = 0; q < n_src; q++) {
-            const uint4 u = src.s[q][k];
-            v.x = u.x > v.x ? u.x : v.x; v.y = u.y > v.y ? u.y : v.y;
-            v.z = u.z > v.z ? u.z : v.z; v.w = u.w > v.w ? u.w : v.w;
+    for (size_t k = (size_t)blockIdx.x * GO_BLOCK + threadIdx.x; k < nv; k += stride) {
+        V v = dst[k];
+        int q = 0;
+        for (; q + FUSE_UNROLL <= n_src; q += FUSE_UNROLL) {
+            V u[FUSE_UNROLL];
+            #pragma unroll
+            for (int j = 0; j < FUSE_UNROLL; j++) u[j] = go_ld_nt(src.s[q + j] + k);
+            #pragma unroll
+            for (int j = 0; j < FUSE_UNROLL; j++) go_fold(v, u[j]);
+        }
+        if (q < n_src) {                       // the last, partial group: still all loads before the first fold
+            V u[FUSE_UNROLL];
+            #pragma unroll
+            for (int j = 0; j < FUSE_UNROLL; j++) if (q + j < n_src) u[j] = go_ld_nt(src.s[q + j] + k);
+            #pragma unroll
+            for (int j = 0; j < FUSE_UNROLL; j++) if (q + j < n_src) go_fold(v, u[j]);
         }
         dst[k] = v;
     }
 }
-__global__ void __launch_bounds__(GO_BLOCK)
-qs_fuse_counts_kernel(ulonglong2 *__restrict__ dst, FuseCnts src, int n_src, size_t n2)
-{
-    const size_t stride = (size_t)gridDim.x * GO_BLOCK;
-    for (size_t k = (size_t)blockIdx.x * GO_BLOCK + threadIdx.x; k < n2; k += stride) {
-        ulonglong2 v = dst[k];
-        for (int q = 0; q < n_src; q++) {
-            const ulonglong2 u = src.s[q][k];
-            v.x += u.x; v.y += u.y;      // hi32/lo32 halves add independently (no carry below 2^32 writes)
-        }
-        dst[k] = v;
-    }
-}
+
+// dst cells [cell_off, cell_off + n_cells) <- fuse(dst, sources); every source pointer names the source's
+// first cell OF THAT RANGE (whole grids: cell_off = 0, n_cells = cells).  cell_off and n_cells are multiples of 4.
 hipError_t qs_launch_fuse(qs_ctx *c, const unsigned int *const *src_stamps,
-                          const unsigned long long *const *src_counts, size_t n_src)
+                          const unsigned long long *const *src_counts, size_t n_src, size_t cell_off, size_t n_cells,
+                          unsigned long long *dst_counts)
 {
     for (size_t base = 0; base < n_src; base += FUSE_MAX_SRC) {
         const int m = (int)((n_src - base < FUSE_MAX_SRC) ? n_src - base : FUSE_MAX_SRC);
         FuseSrcs fs{}; FuseCnts fc{};
-        bool have_counts = c->cfg.enable_counts && src_counts != nullptr;
+        bool have_counts = dst_counts != nullptr && src_counts != nullptr;
+        bool have_stamps = src_stamps != nullptr;
         for (int q = 0; q < m; q++) {
-            fs.s[q] = (const uint4 *)src_stamps[base + q];
+            if (have_stamps) { fs.s[q] = (const uint4 *)src_stamps[base + q]; if (!fs.s[q]) have_stamps = false; }
             if (have_counts) { fc.s[q] = (const ulonglong2 *)src_counts[base + q]; if (!fc.s[q]) have_counts = false; }
         }
-        hipLaunchKernelGGL(qs_fuse_stamps_kernel, dim3(go_blocks(c->cells / 4)), dim3(GO_BLOCK), 0, c->stream,
-                           (uint4 *)c->d_stamps, fs, m, c->cells / 4);
+        if (have_stamps)
+            hipLaunchKernelGGL((qs_fuse_kernel<uint4, FuseSrcs>), dim3(go_blocks(n_cells / 4)), dim3(GO_BLOCK), 0, c->stream,
+                               (uint4 *)(c->d_stamps + cell_off), fs, m, n_cells / 4);
         if (have_counts)
-            hipLaunchKernelGGL(qs_fuse_counts_kernel, dim3(go_blocks(c->cells / 2)), dim3(GO_BLOCK), 0, c->stream,
-                               (ulonglong2 *)c->d_counts, fc, m, c->cells / 2);
+            hipLaunchKernelGGL((qs_fuse_kernel<ulonglong2, FuseCnts>), dim3(go_blocks(n_cells / 2)), dim3(GO_BLOCK), 0, c->stream,
+                               (ulonglong2 *)(dst_counts + cell_off), fc, m, n_cells / 2);
     }
     return hipGetLastError();
 }

@@ -158,6 +158,8 @@ static int reset_state(qs_ctx *c)
     const int nb = c->cfg.max_agent + 1;
     HIPCHK(c, hipMemsetAsync(c->d_stamps, 0, c->cells * sizeof(unsigned int), c->stream));
     if (c->d_counts) HIPCHK(c, hipMemsetAsync(c->d_counts, 0, c->cells * sizeof(unsigned long long), c->stream));
+    if (c->d_counts_fused) HIPCHK(c, hipMemsetAsync(c->d_counts_fused, 0, c->cells * sizeof(unsigned long long), c->stream));
+    c->dirty_since_fuse = false;
     HIPCHK(c, hipMemsetAsync(c->d_drift, 0, (size_t)nb * 2 * sizeof(double), c->stream));
     HIPCHK(c, qs_launch_fill_zone_identity(c));
     HIPCHK(c, hipMemsetAsync(c->d_counters, 0, QS_CNT_N * sizeof(unsigned long long), c->stream));
@@ -183,6 +185,8 @@ extern "C" int qs_create(const qs_config *cfg, qs_ctx **out)
         return qs_fail(nullptr, QS_E_INVAL, "qs_create: bad resolution/origin");
     if (cfg->max_agent < 1 || cfg->max_agent > QS_MAX_AGENT)
         return qs_fail(nullptr, QS_E_INVAL, "qs_create: max_agent must be in [1, 255]");
+    if (cfg->shard_bots < 0 || cfg->shard_rank < 0 || (cfg->shard_bots > 0 && (int64_t)cfg->shard_rank * cfg->shard_bots >= cfg->max_agent))
+        return qs_fail(nullptr, QS_E_INVAL, "qs_create: shard_rank * shard_bots must lie below max_agent");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return qs_fail(nullptr, QS_E_NODEV, "qs_create: no HIP device (this library has no CPU fallback)");
@@ -248,6 +252,7 @@ static void free_batch(qs_ctx *c)
     QsBatch &b = c->b;
     hipFree(b.accept); hipFree(b.agent); hipFree(b.lm); hipFree(b.px); hipFree(b.py); hipFree(b.yaw);
     hipFree(b.dist); hipFree(b.enc); hipFree(b.rx); hipFree(b.ry); hipFree(b.hit); hipFree(b.hit_valid);
+    if (b.map_ok != b.accept) hipFree(b.map_ok);
     memset(&b, 0, sizeof b);
     QsSlamBatch &sb = c->sb;
     hipFree(sb.node); hipFree(sb.ev_node); hipFree(sb.ev_agent); hipFree(sb.ev_type); hipFree(sb.ev_px); hipFree(sb.ev_py);
@@ -264,7 +269,7 @@ extern "C" int qs_destroy(qs_ctx *c)
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto &g : c->h_graphs) graph_free(g);
     free_batch(c);
-    hipFree(c->d_stamps); hipFree(c->d_counts); hipFree(c->d_offset); hipFree(c->d_drift);
+    hipFree(c->d_stamps); hipFree(c->d_counts); hipFree(c->d_counts_fused); hipFree(c->d_io_ws); hipFree(c->d_offset); hipFree(c->d_drift);
     hipFree(c->d_last_closure); hipFree(c->d_zone); hipFree(c->d_counters); hipFree(c->d_graph_batch);
     hipFree(c->d_ekf); hipFree(c->d_ekf_prev); hipFree(c->d_ekf_ws); hipFree(c->d_graphs); hipFree(c->d_pkts); hipFree(c->d_lens);
     hipFree(c->d_time); hipFree(c->d_bin_ws); hipFree(c->d_frontier_ws);
@@ -320,21 +325,7 @@ extern "C" int qs_set_bot_offset(qs_ctx *c, int32_t bot, double off_x)
     return QS_OK;
 }
 
-// ---- timing -------------------------------------------------------------------------------
-static hipEvent_t ev_get(qs_ctx *c)
-{
-    if (!c->ev_pool.empty()) { hipEvent_t e = c->ev_pool.back(); c->ev_pool.pop_back(); return e; }
-    hipEvent_t e = nullptr;
-    hipEventCreate(&e);
-    return e;
-}
-struct StageTimer {
-    qs_ctx *c; int stage; hipStream_t st; hipEvent_t a = nullptr, b = nullptr;
-    StageTimer(qs_ctx *c_, int s, hipStream_t st_ = nullptr) : c(c_), stage(s), st(st_ ? st_ : c_->stream)
-    { if (c->timing) { a = ev_get(c); b = ev_get(c); hipEventRecord(a, st); } }
-    void stop() { if (c->timing && a) { hipEventRecord(b, st); c->pending.push_back({stage, a, b}); a = nullptr; } }
-};
-
+// ---- timing (StageTimer: qs_internal.h) -----------------------------------------------------------
 extern "C" int qs_timing_enable(qs_ctx *c, int32_t enable)
 {
     ARGCHK(c, c != nullptr);
@@ -371,6 +362,12 @@ static int ensure_batch(qs_ctx *c, size_t n)
     HIPCHK(c, dev_realloc(&b.dist, cap)); HIPCHK(c, dev_realloc(&b.enc, cap));
     HIPCHK(c, dev_realloc(&b.rx, cap)); HIPCHK(c, dev_realloc(&b.ry, cap));
     HIPCHK(c, dev_realloc(&b.hit, 4 * cap)); HIPCHK(c, dev_realloc(&b.hit_valid, 4 * cap));
+    if (c->cfg.shard_bots > 0) {
+        if (b.map_ok == b.accept) b.map_ok = nullptr;        // (accept was re-allocated above)
+        HIPCHK(c, dev_realloc(&b.map_ok, cap));
+        b.own_lo = c->cfg.shard_rank * c->cfg.shard_bots + 1;
+        b.own_hi = std::min(c->cfg.max_agent, (c->cfg.shard_rank + 1) * c->cfg.shard_bots);
+    } else { b.map_ok = b.accept; b.own_lo = 1; b.own_hi = c->cfg.max_agent; }
     QsSlamBatch &sb = c->sb;
     const size_t nblk = (size_t)qs_slam_blocks(cap), G = (size_t)c->n_graphs, nb = (size_t)c->cfg.max_agent + 2;
     HIPCHK(c, dev_realloc(&sb.node, cap)); HIPCHK(c, dev_realloc(&sb.ev_node, cap));
@@ -386,16 +383,42 @@ static int ensure_batch(qs_ctx *c, size_t n)
 }
 
 // Stamp ordinals are 30 bits (so stamps stay below 2^31 and an int32 MAX all-reduce is valid).
+static const uint64_t QS_EPOCH_LIMIT = (1ull << 28) - 2;
+static bool epoch_would_rebase(const qs_ctx *c, uint64_t seq0, size_t n_seq)
+{
+    return seq0 + n_seq - c->epoch_base > QS_EPOCH_LIMIT;
+}
 static int ensure_epoch(qs_ctx *c, uint64_t seq0, size_t n_seq)
 {
     if (seq0 < c->epoch_base) return qs_fail(c, QS_E_INVAL, "seq0 precedes the current stamp epoch (sequence numbers must not decrease)");
-    const uint64_t limit = (1ull << 28) - 2;
-    if (n_seq > limit) return qs_fail(c, QS_E_RANGE, "batch too large for one stamp epoch (2^28 records)");
-    if (seq0 + n_seq - c->epoch_base > limit) {
+    if (n_seq > QS_EPOCH_LIMIT) return qs_fail(c, QS_E_RANGE, "batch too large for one stamp epoch (2^28 records)");
+    if (epoch_would_rebase(c, seq0, n_seq)) {
+        // A rebase collapses every written cell to ordinal 1.  In one mapper that keeps the order against all later
+        // writes; in a shard of a round-robin stream (seq_stride > 1) two ranks' unfused writes to one cell would tie
+        // afterwards, so the shards must have exchanged their stamps first (dist.ShardedMapper does: it asks
+        // qs_epoch_query before every ingest).
+        if (c->cfg.seq_stride > 1 && c->dirty_since_fuse)
+            return qs_fail(c, QS_E_STATE, "this batch crosses a stamp epoch: fuse the shards' grids (all-reduce + qs_mark_fused) first");
         HIPCHK(c, qs_launch_rebase(c));
         c->epoch_base = seq0 ? seq0 - 1 : 0;
         c->n_rebases++;
     }
+    return QS_OK;
+}
+
+extern "C" int qs_epoch_query(qs_ctx *c, uint64_t seq0, size_t n, int32_t *would_rebase)
+{
+    ARGCHK(c, c != nullptr && would_rebase != nullptr);
+    if (seq0 == UINT64_MAX) seq0 = c->next_seq;
+    const uint64_t sstride = c->cfg.seq_stride > 0 ? (uint64_t)c->cfg.seq_stride : 1;
+    *would_rebase = (n > 0 && epoch_would_rebase(c, seq0 - seq0 % sstride, n * sstride)) ? 1 : 0;
+    return QS_OK;
+}
+
+extern "C" int qs_mark_fused(qs_ctx *c)
+{
+    ARGCHK(c, c != nullptr);
+    c->dirty_since_fuse = false;
     return QS_OK;
 }
 
@@ -493,6 +516,7 @@ static int ingest_device(qs_ctx *c, const uint8_t *d_pkts, size_t n, size_t stri
     }
     if (c->cfg.enable_ekf) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_ekf_done, 0));   // join
     c->next_seq = seq0 + n * sstride;
+    c->dirty_since_fuse = true;
     return QS_OK;
 }
 
@@ -574,6 +598,18 @@ extern "C" int qs_last_hits(qs_ctx *c, double *xy, uint8_t *valid, size_t n)
 }
 
 // ---- OccupancyGrid object API ---------------------------------------------------------------
+static int io_reserve(qs_ctx *c, size_t bytes)
+{
+    if (bytes <= c->io_ws_bytes) return QS_OK;
+    size_t cap = c->io_ws_bytes ? c->io_ws_bytes : (1u << 16);
+    while (cap < bytes) cap *= 2;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->d_io_ws) { HIPCHK(c, hipFree(c->d_io_ws)); c->d_io_ws = nullptr; c->io_ws_bytes = 0; }
+    HIPCHK(c, hipMalloc(&c->d_io_ws, cap));
+    c->io_ws_bytes = cap;
+    return QS_OK;
+}
+
 extern "C" int qs_update_rays(qs_ctx *c, const double *rx, const double *ry, const double *hx, const double *hy,
                               const uint8_t *valid, size_t n, uint64_t seq0)
 {
@@ -585,9 +621,10 @@ extern "C" int qs_update_rays(qs_ctx *c, const double *rx, const double *ry, con
     const size_t n_seq = (n + 3) / 4;
     int rc = ensure_epoch(c, seq0, n_seq);
     if (rc != QS_OK) return rc;
-    double *d = nullptr; unsigned char *dv = nullptr;
-    HIPCHK(c, hipMalloc((void **)&d, 4 * n * sizeof(double)));
-    HIPCHK(c, hipMalloc((void **)&dv, n));
+    // staging lives with the context (grown on demand): the object API's update_ray is one ray per call
+    int rc2 = io_reserve(c, 4 * n * sizeof(double) + n);
+    if (rc2 != QS_OK) return rc2;
+    double *d = (double *)c->d_io_ws; unsigned char *dv = (unsigned char *)(d + 4 * n);
     hipError_t e = hipSuccess;
     const double *src[4] = {rx, ry, hx, hy};
     for (int q = 0; q < 4 && e == hipSuccess; q++)
@@ -595,8 +632,8 @@ extern "C" int qs_update_rays(qs_ctx *c, const double *rx, const double *ry, con
     if (e == hipSuccess) e = hipMemcpyAsync(dv, valid, n, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = qs_launch_update_rays(c, d, d + n, d + 2 * n, d + 3 * n, dv, n, seq0);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    hipFree(d); hipFree(dv);
     if (e != hipSuccess) return qs_fail(c, QS_E_HIP, "qs_update_rays", e);
+    c->dirty_since_fuse = true;
     c->next_seq = seq0 + n_seq;
     c->last_has_poses = false;
     return QS_OK;
@@ -846,13 +883,52 @@ extern "C" int qs_zone_packet(qs_ctx *c, int32_t bot, int32_t online, uint8_t ou
 }
 
 // ---- fuse / merge ---------------------------------------------------------------------------------
+extern "C" int qs_fuse_buffers_range(qs_ctx *c, const void *const *stamps_dev, const void *const *counts_dev, size_t n,
+                                     size_t cell_offset, size_t n_cells, int32_t counts_into_fused)
+{
+    ARGCHK(c, c != nullptr);
+    if (n == 0 || n_cells == 0) return QS_OK;
+    ARGCHK(c, stamps_dev != nullptr || counts_dev != nullptr);
+    ARGCHK(c, cell_offset % 4 == 0 && n_cells % 4 == 0 && cell_offset + n_cells <= c->cells);
+    if (counts_dev && counts_into_fused && !c->d_counts_fused)
+        return qs_fail(c, QS_E_INVAL, "qs_fuse_buffers_range: no fused counter snapshot (call qs_fused_counts first)");
+    HIPCHK(c, hipSetDevice(c->device));
+    unsigned long long *dc = c->cfg.enable_counts ? (counts_into_fused ? c->d_counts_fused : c->d_counts) : nullptr;
+    HIPCHK(c, qs_launch_fuse(c, (const unsigned int *const *)stamps_dev, (const unsigned long long *const *)counts_dev, n,
+                             cell_offset, n_cells, dc));
+    return QS_OK;
+}
+
 extern "C" int qs_fuse_buffers(qs_ctx *c, const void *const *stamps_dev, const void *const *counts_dev, size_t n)
 {
     ARGCHK(c, c != nullptr);
     if (n == 0) return QS_OK;
     ARGCHK(c, stamps_dev != nullptr);
+    return qs_fuse_buffers_range(c, stamps_dev, counts_dev, n, 0, c->cells, 0);
+}
+
+// Counters are per-context sums of this context's own writes.  A collective must not add into them (a second
+// all-reduce would add the peers' totals again): it sums a SNAPSHOT.  This call copies the local counters into the
+// context's second buffer (allocated on first use) on the context's stream and returns it; the caller sums it over the
+// ranks in place.  qs_counts_source(ctx, 1) points the counter / log-odds views at it.
+extern "C" int qs_fused_counts(qs_ctx *c, void **fused_dev, size_t *bytes)
+{
+    ARGCHK(c, c != nullptr && fused_dev != nullptr);
+    if (!c->d_counts) return qs_fail(c, QS_E_INVAL, "qs_fused_counts: context created with enable_counts = 0");
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, qs_launch_fuse(c, (const unsigned int *const *)stamps_dev, (const unsigned long long *const *)counts_dev, n));
+    const size_t nb = c->cells * sizeof(unsigned long long);
+    if (!c->d_counts_fused) HIPCHK(c, hipMalloc((void **)&c->d_counts_fused, nb));
+    HIPCHK(c, hipMemcpyAsync(c->d_counts_fused, c->d_counts, nb, hipMemcpyDeviceToDevice, c->stream));
+    *fused_dev = c->d_counts_fused;
+    if (bytes) *bytes = nb;
+    return QS_OK;
+}
+
+extern "C" int qs_counts_source(qs_ctx *c, int32_t fused)
+{
+    ARGCHK(c, c != nullptr);
+    if (fused && !c->d_counts_fused) return qs_fail(c, QS_E_INVAL, "qs_counts_source: no fused snapshot yet (qs_fused_counts)");
+    c->counts_view_fused = fused != 0;
     return QS_OK;
 }
 
@@ -868,7 +944,7 @@ extern "C" int qs_fuse(qs_ctx *dst, qs_ctx *const *srcs, size_t n)
         if (!s || s->device != dst->device || s->cfg.size != dst->cfg.size || s->cfg.res != dst->cfg.res ||
             s->cfg.ox != dst->cfg.ox || s->cfg.oy != dst->cfg.oy)
             return qs_fail(dst, QS_E_INVAL, "qs_fuse: source grids must share device and geometry with dst");
-        if (s->epoch_base != dst->epoch_base)
+        if (s->epoch_base != dst->epoch_base || s->n_rebases != dst->n_rebases)
             return qs_fail(dst, QS_E_INVAL, "qs_fuse: source and destination are in different stamp epochs");
         HIPCHK(dst, hipStreamSynchronize(s->stream));
         st[i] = s->d_stamps; ct[i] = s->d_counts;

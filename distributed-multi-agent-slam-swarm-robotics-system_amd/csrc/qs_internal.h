@@ -90,6 +90,9 @@ struct QsGeom {
 struct QsBatch {
     size_t n;
     unsigned char *accept;   // 1 = passes dual_bot_mapper.py:826-843
+    unsigned char *map_ok;   // 1 = accepted AND this context casts its rays / runs its filter: the same array as accept
+                             // unless the context is one shard of a replicated-pose-graph deployment (qs_config.shard_bots)
+    int own_lo, own_hi;      // agents whose rays this context casts (1..max_agent when not sharded)
     unsigned char *agent;    // agent_id
     unsigned char *lm;       // landmark_type (0 for v1 packets)
     double *px, *py, *yaw;   // f32 fields widened; px already has the bot offset (:851-852)
@@ -114,7 +117,10 @@ struct qs_ctx {
     QsGeom geom;
 
     unsigned int *d_stamps = nullptr;            // [size][size]; 0 = UNKNOWN, else (ordinal<<1)|occ
-    unsigned long long *d_counts = nullptr;      // [size][size]; hi32 = hits, lo32 = misses
+    unsigned long long *d_counts = nullptr;      // [size][size]; hi32 = hits, lo32 = misses (this context's own writes)
+    unsigned long long *d_counts_fused = nullptr; // [size][size]; snapshot of d_counts that a collective sums over the ranks
+    bool counts_view_fused = false;              // qs_grid_counts / qs_grid_logodds read the fused snapshot
+    bool dirty_since_fuse = false;               // cells written since the last qs_mark_fused (sharded streams: rebase guard)
     double *d_offset = nullptr;                  // [max_agent+1]
     double *d_drift = nullptr;                   // [max_agent+1][2]
     long long *d_last_closure = nullptr;         // [max_agent+1]
@@ -143,6 +149,7 @@ struct qs_ctx {
     // tile-binned raycast workspace
     void *d_bin_ws = nullptr; size_t bin_ws_bytes = 0;
     void *d_frontier_ws = nullptr;               // frontier labelling workspace (allocated on first use)
+    void *d_io_ws = nullptr; size_t io_ws_bytes = 0;     // staging of the object-API calls (qs_update_rays, views), grown on demand
     void *d_ekf_ws = nullptr; size_t ekf_ws_bytes = 0;   // parallel-in-time EKF workspace (ekf_scan.hip)
 
     uint64_t next_seq = 0, epoch_base = 0, n_rebases = 0;
@@ -154,6 +161,21 @@ struct qs_ctx {
     std::vector<hipEvent_t> ev_pool;
     double stage_ms[QS_STAGE_N]{};
     uint64_t stage_launches[QS_STAGE_N]{};
+};
+
+// ---- HIP-event timing of stages and of single kernels, on the stream they are launched on -------
+static inline hipEvent_t qs_ev_get(qs_ctx *c)
+{
+    if (!c->ev_pool.empty()) { hipEvent_t e = c->ev_pool.back(); c->ev_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    hipEventCreate(&e);
+    return e;
+}
+struct StageTimer {
+    qs_ctx *c; int stage; hipStream_t st; hipEvent_t a = nullptr, b = nullptr;
+    StageTimer(qs_ctx *c_, int s, hipStream_t st_ = nullptr) : c(c_), stage(s), st(st_ ? st_ : c_->stream)
+    { if (c->timing) { a = qs_ev_get(c); b = qs_ev_get(c); hipEventRecord(a, st); } }
+    void stop() { if (c->timing && a) { hipEventRecord(b, st); c->pending.push_back({stage, a, b}); a = nullptr; } }
 };
 
 // ---- kernel launchers (each defined next to its kernel) ----------------------------------
@@ -183,7 +205,8 @@ hipError_t qs_launch_logodds(qs_ctx *c, float l_occ, float l_free, float lmin, f
 hipError_t qs_launch_split_counts(qs_ctx *c, int *hits_dev, int *misses_dev);
 hipError_t qs_launch_rebase(qs_ctx *c);
 hipError_t qs_launch_fuse(qs_ctx *c, const unsigned int *const *d_src_stamps,
-                          const unsigned long long *const *d_src_counts, size_t n_src);
+                          const unsigned long long *const *d_src_counts, size_t n_src, size_t cell_off, size_t n_cells,
+                          unsigned long long *dst_counts);
 hipError_t qs_launch_fill_zone_identity(qs_ctx *c);
 hipError_t qs_launch_grid_to_pcd(qs_ctx *c, const signed char *d_grid, int h, int w, double res,
                                  double ox, double oy, double *d_xy, size_t cap,

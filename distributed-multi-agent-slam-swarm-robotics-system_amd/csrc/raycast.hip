@@ -33,7 +33,7 @@ qs_raycast_direct_kernel(size_t n, QsBatch b, QsGeom geo, unsigned int *__restri
     const size_t i = r >> 2;
     const int s = (int)(r & 3);
     unsigned int my_cells = 0, my_ray = 0, my_hit = 0;
-    if (i < n && b.accept[i]) {
+    if (i < n && b.map_ok[i]) {
         const double rx = b.rx[i], ry = b.ry[i], yaw = b.yaw[i];
         const float4 d4 = b.dist[i];
         const float df = s == 0 ? d4.x : (s == 1 ? d4.y : (s == 2 ? d4.z : d4.w));
@@ -172,7 +172,7 @@ qs_hits_kernel(size_t n, QsBatch b, QsGeom geo)
     if (i >= n) return;
     double2 h = make_double2(0.0, 0.0);
     unsigned char v = 0;
-    if (b.accept[i]) {
+    if (b.map_ok[i]) {
         const QsRay ray = qs_project_ray(b.rx[i], b.ry[i], b.yaw[i], (double)((const float *)b.dist)[r], (int)(r & 3), geo);
         h = make_double2(ray.ex, ray.ey);
         v = ray.valid ? 1 : 0;

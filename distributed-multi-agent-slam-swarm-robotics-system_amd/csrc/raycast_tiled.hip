@@ -101,7 +101,7 @@ qs_rays_kernel(size_t n, QsBatch b, QsGeom geo, QtWorkspace ws, unsigned int *__
     float df_n = 0;
     if (r0 + tid < r1) {
         const size_t r = r0 + tid, i = r >> 2;
-        acc_n = b.accept[i]; agent_n = b.agent[i]; rx_n = b.rx[i]; ry_n = b.ry[i]; yaw_n = b.yaw[i];
+        acc_n = b.map_ok[i]; agent_n = b.agent[i]; rx_n = b.rx[i]; ry_n = b.ry[i]; yaw_n = b.yaw[i];
         df_n = ((const float *)b.dist)[r];
     }
     for (size_t r = r0 + tid; r < r1; r += QT_BIN_BLOCK) {
@@ -113,7 +113,7 @@ qs_rays_kernel(size_t n, QsBatch b, QsGeom geo, QtWorkspace ws, unsigned int *__
         const float df = df_n;
         if (r + QT_BIN_BLOCK < r1) {
             const size_t rn = r + QT_BIN_BLOCK, in = rn >> 2;
-            acc_n = b.accept[in]; agent_n = b.agent[in]; rx_n = b.rx[in]; ry_n = b.ry[in]; yaw_n = b.yaw[in];
+            acc_n = b.map_ok[in]; agent_n = b.agent[in]; rx_n = b.rx[in]; ry_n = b.ry[in]; yaw_n = b.yaw[in];
             df_n = ((const float *)b.dist)[rn];
         }
         uint2 rec = make_uint2((unsigned int)QT_NO_RAY & 0xffffu, 0u);
@@ -524,6 +524,7 @@ hipError_t qs_launch_raycast_tiled(qs_ctx *c, size_t n, uint64_t seq0)
         if (ea == hipSuccess) ea = hipFuncSetAttribute((const void *)qs_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (ea != hipSuccess) return ea;
     }
+    StageTimer t_rays(c, QS_STAGE_RC_RAYS);
     if (c->cfg.enable_counts) {
         hipLaunchKernelGGL(qs_rays_kernel<true>, dim3(ws.nwg), dim3(QT_BIN_BLOCK), lds, c->stream, n, c->b, c->geom, ws,
                            c->d_stamps, c->d_counts, ord_base, ord_stride, c->d_zone, c->cfg.max_agent, c->d_counters);
@@ -531,19 +532,24 @@ hipError_t qs_launch_raycast_tiled(qs_ctx *c, size_t n, uint64_t seq0)
         hipLaunchKernelGGL(qs_rays_kernel<false>, dim3(ws.nwg), dim3(QT_BIN_BLOCK), lds, c->stream, n, c->b, c->geom, ws,
                            c->d_stamps, c->d_counts, ord_base, ord_stride, c->d_zone, c->cfg.max_agent, c->d_counters);
     }
+    t_rays.stop();
+    StageTimer t_sort(c, QS_STAGE_RC_SORT);
     hipLaunchKernelGGL(qs_table_scan_kernel, dim3((ws.n_tiles + QT_SCAN_TILES - 1) / QT_SCAN_TILES),
                        dim3(QT_SCAN_TILES * QT_SCAN_SEGS), 0, c->stream, ws);
     hipLaunchKernelGGL(qs_scatter_kernel, dim3(ws.nwg), dim3(QT_BIN_BLOCK), lds, c->stream, n, c->b, ws,
                        c->cfg.size, ord_base, ord_stride);
+    t_sort.stop();
     // QS_RASTER_WGS (environment, read once): fewer persistent raster workgroups than the default -- a tuning
     // knob, and how the tests reach the long-run paths (tile changes inside a run, the 31-item flush)
     static const int env_wgs = [] { const char *e = getenv("QS_RASTER_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : QT_RASTER_WGS; }();
     const unsigned int raster_wgs = (unsigned int)(max_items < (size_t)env_wgs ? max_items : (size_t)env_wgs);
+    StageTimer t_raster(c, QS_STAGE_RC_RASTER);
     if (c->cfg.enable_counts)
         hipLaunchKernelGGL(qs_raster_kernel<true>, dim3(raster_wgs), dim3(QT_BLOCK), 0, c->stream, ws,
                            c->cfg.size, c->d_stamps, c->d_counts, c->d_counters);
     else
         hipLaunchKernelGGL(qs_raster_kernel<false>, dim3(raster_wgs), dim3(QT_BLOCK), 0, c->stream, ws,
                            c->cfg.size, c->d_stamps, c->d_counts, c->d_counters);
+    t_raster.stop();
     return hipGetLastError();
 }

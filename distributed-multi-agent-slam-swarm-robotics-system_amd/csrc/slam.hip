@@ -816,6 +816,7 @@ hipError_t qs_launch_slam(qs_ctx *c, size_t n, bool raw_pose)
     hipLaunchKernelGGL(qs_slam_prefix_kernel, dim3(1), dim3(256), 0, c->stream, sb, G, c->cfg.max_agent, c->d_drift);
     hipLaunchKernelGGL(qs_slam_index_kernel, dim3(sb.n_blocks), dim3(IDX_BLOCK), (size_t)IDX_WAVES * G * 2 * sizeof(unsigned int),
                        c->stream, n, c->b, sb, c->d_graphs, c->bots_per_graph, G);
+    StageTimer t_chain(c, QS_STAGE_SLAM_CHAIN);
     if (c->bots_per_graph <= CH_AGW)
         hipLaunchKernelGGL(qs_slam_chain_kernel<true>, dim3(G), dim3(CH_THREADS), 0, c->stream, c->d_graphs, sb, c->bg,
                            c->bots_per_graph, c->cfg.max_agent, c->win, c->cfg.min_poses_between, c->r2_threshold,
@@ -824,6 +825,7 @@ hipError_t qs_launch_slam(qs_ctx *c, size_t n, bool raw_pose)
         hipLaunchKernelGGL(qs_slam_chain_kernel<false>, dim3(G), dim3(CH_THREADS), 0, c->stream, c->d_graphs, sb, c->bg,
                            c->bots_per_graph, c->cfg.max_agent, c->win, c->cfg.min_poses_between, c->r2_threshold,
                            c->cfg.closure_correction, c->d_drift, c->d_last_closure, c->d_counters, raw_pose ? 1 : 0);
+    t_chain.stop();
     if (raw_pose) return hipGetLastError();
     hipLaunchKernelGGL(qs_slam_pose_kernel, dim3((unsigned int)((n + 255) / 256)), dim3(256), 0, c->stream, n, c->b, sb);
     return hipGetLastError();

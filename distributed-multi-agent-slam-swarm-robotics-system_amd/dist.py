@@ -4,7 +4,25 @@ One process per GPU (torch.distributed, backend "nccl" = RCCL on ROCm).  Every r
 own bots' packets into a full-size local stamp grid; because a stamp carries the packet's GLOBAL
 arrival index, the cell-wise MAX of the per-rank grids is bit-identical to one mapper fed the
 interleaved stream (shared-grid semantics of dual_bot_mapper.py:785).  Hit/miss counters add.
-torch is plumbing here: device memory views and the collective, no arithmetic.
+torch is plumbing here: device memory views and the collectives, no arithmetic.
+
+Two things differ between the ranks' streams and one mapper's, and each has a mode here:
+
+* the pose graph.  PoseGraphSLAM is global across bots in the reference (node.index counts every bot's
+  poses, :275; a landmark of one bot can close another's loop, :294-309).
+  - mode "per_shard": every rank keeps the pose graph(s) of its own bots (a shard = one mapper instance; with the
+    reference's 2-bot limit, "one pose graph per mapper process" is the deployment unit).  No exchange before the fuse.
+  - mode "replicated": ONE pose graph over all bots.  The ranks all-gather the batch's raw datagrams (42 B each), every
+    rank decodes and runs the loop-closure chain over the whole interleaved stream -- identical work, identical drifts
+    everywhere -- and casts rays only for its own agents (qs_config.shard_bots / shard_rank).  Result = one mapper fed
+    the interleaved stream, bit for bit; the chain does not scale with ranks (it is the reference's recurrence).
+* the counters.  They are per-rank sums of the rank's own writes and are never all-reduced in place (a second
+  all-reduce would add the peers' totals again): the collective sums a snapshot (qs_fused_counts).
+
+Fuse algorithms: "allreduce" = RCCL's all-reduce (ring/tree, its choice); "direct" = reduce-scatter by
+point-to-point exchange + local fold (the K3 kernel, qs_fuse_buffers_range) + all-gather: on a fully connected xGMI
+node every rank sends 1/N of the grid to each of its N-1 peers at once, so all seven links carry traffic in both phases
+(SURVEY.md section 5), where a ring is bound by one link.
 """
 import numpy as np
 
@@ -28,18 +46,165 @@ def grid_tensors(mapper, device):
     return stamps, counts
 
 
+def fused_counts_tensor(mapper, device):
+    """Snapshot the local counters (qs_fused_counts) -> int32 [size,size,2] aliasing the snapshot."""
+    import torch
+    p, _ = mapper.fused_counts()
+    n = mapper.size
+    return torch.as_tensor(_DevArray(p, (n, n, 2), "<i4"), device=device)
+
+
 def allreduce_tensors(stamps, counts=None, group=None):
-    """The fuse rule on plain tensors (any backend): latest stamp wins, counters add."""
+    """The fuse rule on plain tensors (any backend): latest stamp wins, counters add.  `counts` must be a SNAPSHOT
+    of the rank's counters (or a tensor that is summed only once): the sum lands in place."""
     import torch.distributed as dist
     dist.all_reduce(stamps, op=dist.ReduceOp.MAX, group=group)
     if counts is not None:
         dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
 
 
-def allreduce_grids(mapper, device, group=None, counts=True):
-    """Fuse every rank's grid into the global map, in place on all ranks (RCCL over xGMI)."""
-    stamps, cnt = grid_tensors(mapper, device)
-    allreduce_tensors(stamps, cnt if counts else None, group)
+def reduce_scatter_allgather(t, fold, group=None):
+    """Direct all-reduce of a contiguous tensor whose element count divides by the world size:
+       1. every rank sends slice p of its tensor to rank p and receives its peers' copies of its own slice
+          (N-1 sends + N-1 receives, all in flight together: one batch_isend_irecv);
+       2. fold(offset, n, recv) folds the received copies (recv: [N-1, n]) into t.view(-1)[offset : offset + n];
+       3. all-gather of the folded slices, in place.
+    `fold` is the K3 kernel on the GPU (ShardedMapper) and a torch reduction in the CPU tests."""
+    import torch
+    import torch.distributed as dist
+    W, r = dist.get_world_size(group), dist.get_rank(group)
+    flat = t.view(-1)
+    if W == 1:
+        return
+    assert flat.numel() % W == 0, "tensor size must divide by the world size"
+    n = flat.numel() // W
+    recv = torch.empty((W - 1, n), dtype=flat.dtype, device=flat.device)
+    peers = [p for p in range(W) if p != r]
+    ops = []
+    for k, p in enumerate(peers):
+        gp = dist.get_global_rank(group, p) if group is not None else p
+        ops.append(dist.P2POp(dist.isend, flat[p * n:(p + 1) * n], gp, group))
+        ops.append(dist.P2POp(dist.irecv, recv[k], gp, group))
+    for w in dist.batch_isend_irecv(ops):
+        w.wait()
+    fold(r * n, n, recv)
+    mine = flat[r * n:(r + 1) * n]
+    if flat.is_cuda:
+        dist.all_gather_into_tensor(flat, mine, group=group)          # in place: input is slice r of the output
+    else:
+        parts = [torch.empty_like(mine) for _ in range(W)]            # gloo has no in-place form
+        dist.all_gather(parts, mine.clone(), group=group)
+        for p in range(W):
+            flat[p * n:(p + 1) * n] = parts[p]
+
+
+def allreduce_grids(mapper, device, group=None, counts=True, algo="allreduce", sync=True):
+    """Fuse every rank's grid into the global map (RCCL over xGMI).  Stamps: MAX in place on all ranks (idempotent:
+    a later call, or a later local write, keeps the order).  Counters: the sum of the ranks' SNAPSHOTS lands in each
+    context's fused buffer (mapper.counts_source(True) is set, so counts()/logodds() read the global map); the local
+    counters are untouched and the call may be repeated after every batch.  Returns the fused counts tensor or None.
+    `sync`: wait for the context's stream first (not needed when it is torch's current stream)."""
+    import torch
+    if sync:
+        mapper.sync()
+    stamps, local = grid_tensors(mapper, device)
+    fused = fused_counts_tensor(mapper, device) if (counts and local is not None) else None
+    if sync and fused is not None:
+        mapper.sync()                 # the snapshot copy runs on the context's stream
+    if algo == "direct":
+        cells = mapper.size * mapper.size
+
+        def fold_stamps(off, n, recv):
+            base = recv.data_ptr()
+            if sync:
+                torch.cuda.current_stream().synchronize()      # the receives complete on torch's stream
+            mapper.fuse_buffers_range([base + k * n * 4 for k in range(recv.shape[0])], None, off, n)
+            if sync:
+                mapper.sync()
+
+        def fold_counts(off, n, recv):          # recv: int32 [N-1, 2*cells/N]; offsets in int32 units -> cells
+            base = recv.data_ptr()
+            if sync:
+                torch.cuda.current_stream().synchronize()
+            mapper.fuse_buffers_range(None, [base + k * n * 4 for k in range(recv.shape[0])], off // 2, n // 2,
+                                      counts_into_fused=True)
+            if sync:
+                mapper.sync()
+
+        import torch.distributed as dist
+        W = dist.get_world_size(group)
+        if cells % (4 * W) != 0:
+            raise ValueError("direct fuse: size*size must divide by 4 * world size")
+        reduce_scatter_allgather(stamps, fold_stamps, group)
+        if fused is not None:
+            reduce_scatter_allgather(fused, fold_counts, group)
+    else:
+        allreduce_tensors(stamps, fused, group)
+    mapper.mark_fused()
+    if fused is not None:
+        mapper.counts_source(True)
+    return fused
+
+
+class ShardedMapper:
+    """One rank of an N-way deployment of the central mapper (one process per GPU).
+
+    per_shard:   mapper created with seq_stride = world; record i of this rank's batch is global record
+                 seq_base + i*world + rank (N equal streams interleaved round-robin).
+    replicated:  mapper created with shard_bots / shard_rank, seq_stride = 1, max_agent = all bots (<= 255: agent_id is
+                 one byte on the wire and the global pose graph needs globally unique ids); the batch is all-gathered
+                 and every rank ingests the interleaved whole.
+    """
+
+    def __init__(self, mapper, device, rank, world, group=None, mode="per_shard", fuse="allreduce", same_stream=True):
+        if mode not in ("per_shard", "replicated"):
+            raise ValueError("mode must be per_shard or replicated")
+        if mode == "per_shard" and world > 1 and mapper.cfg.seq_stride != world:
+            raise ValueError("per_shard mode: create the mapper with seq_stride = world size")
+        if mode == "replicated" and (mapper.cfg.seq_stride not in (0, 1) or (world > 1 and mapper.cfg.shard_bots <= 0)):
+            raise ValueError("replicated mode: create the mapper with seq_stride = 1 and shard_bots > 0")
+        self.m, self.device, self.rank, self.world, self.group = mapper, device, rank, world, group
+        self.mode, self.fuse_algo, self.same_stream = mode, fuse, same_stream
+        self._gather = None
+
+    def ingest(self, d_pkts, d_time=None, seq_base=0):
+        """d_pkts: uint8 [B, stride] device tensor (this rank's batch); d_time: float64 [B] or None;
+        seq_base: global arrival index of record 0 of rank 0's batch.  Asynchronous."""
+        import torch
+        import torch.distributed as dist
+        B, stride = d_pkts.shape
+        if self.mode == "per_shard" or self.world == 1:
+            seq0 = seq_base + (self.rank if self.mode == "per_shard" else 0)
+            if self.world > 1 and self.m.epoch_would_rebase(B, seq0):
+                self.fuse(counts=False)          # the shards exchange their stamps before the grid is rebased
+            self.m.ingest_device(d_pkts.data_ptr(), B, stride, 0, d_time.data_ptr() if d_time is not None else 0, seq0=seq0)
+            return B
+        W = self.world
+        if self._gather is None or self._gather[0].shape != (W, B, stride):
+            self._gather = (torch.empty((W, B, stride), dtype=torch.uint8, device=d_pkts.device),
+                            torch.empty((W, B), dtype=torch.float64, device=d_pkts.device))
+        g_p, g_t = self._gather
+        dist.all_gather_into_tensor(g_p.view(-1), d_pkts.contiguous().view(-1), group=self.group)
+        full = g_p.permute(1, 0, 2).contiguous().view(W * B, stride)       # round-robin interleave: record i*W + r
+        t_ptr = 0
+        if d_time is not None:
+            dist.all_gather_into_tensor(g_t.view(-1), d_time.contiguous().view(-1), group=self.group)
+            full_t = g_t.permute(1, 0).contiguous().view(-1)
+            t_ptr = full_t.data_ptr()
+            self._keep = (full, full_t)
+        else:
+            self._keep = (full,)
+        if not self.same_stream:
+            torch.cuda.current_stream().synchronize()
+        self.m.ingest_device(full.data_ptr(), W * B, stride, 0, t_ptr, seq0=seq_base)
+        return W * B
+
+    def fuse(self, counts=True):
+        if self.world == 1:
+            self.m.mark_fused()
+            return None
+        return allreduce_grids(self.m, self.device, self.group, counts=counts, algo=self.fuse_algo,
+                               sync=not self.same_stream)
 
 
 def tri_state_from_stamps(stamps):

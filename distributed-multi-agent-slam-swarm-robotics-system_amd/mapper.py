@@ -27,7 +27,7 @@ class QuasarMapper:
                  enable_counts=True, enable_ekf=False, device=0, raycast_mode=0,
                  ekf_metres_per_tick=0.0107, min_poses_between=P.MIN_POSES_BETWEEN,
                  closure_radius=P.CLOSURE_RADIUS, closure_correction=P.CLOSURE_CORRECTION,
-                 seq_stride=1):
+                 seq_stride=1, shard_bots=0, shard_rank=0):
         self._L = _lib.load()
         cfg = QsConfig()
         check(None, self._L.qs_config_default(C.byref(cfg)), "qs_config_default")
@@ -40,6 +40,7 @@ class QuasarMapper:
         cfg.min_poses_between = min_poses_between
         cfg.closure_radius, cfg.closure_correction = closure_radius, closure_correction
         cfg.seq_stride = seq_stride
+        cfg.shard_bots, cfg.shard_rank = shard_bots, shard_rank
         self.cfg = cfg
         self.size, self.res, self.ox, self.oy = size, resolution, origin_x, origin_y
         self.max_agent = max_agent
@@ -247,6 +248,33 @@ class QuasarMapper:
         sp = (C.c_void_p * n)(*stamp_ptrs)
         cp = (C.c_void_p * n)(*count_ptrs) if count_ptrs else None
         self._chk(self._L.qs_fuse_buffers(self._h, sp, cp, n), "qs_fuse_buffers")
+
+    def fuse_buffers_range(self, stamp_ptrs, count_ptrs, cell_offset, n_cells, counts_into_fused=False):
+        """Fold peers' copies of cells [cell_offset, cell_offset + n_cells) into this grid (raw device addresses of the
+        first cell of the range; either list may be None)."""
+        n = len(stamp_ptrs if stamp_ptrs else count_ptrs)
+        sp = (C.c_void_p * n)(*stamp_ptrs) if stamp_ptrs else None
+        cp = (C.c_void_p * n)(*count_ptrs) if count_ptrs else None
+        self._chk(self._L.qs_fuse_buffers_range(self._h, sp, cp, n, cell_offset, n_cells, int(counts_into_fused)),
+                  "qs_fuse_buffers_range")
+
+    def fused_counts(self):
+        """Snapshot the local counters into the context's second buffer -> (device address, bytes); a collective sums
+        that buffer over the ranks (never the local counters themselves)."""
+        p, b = C.c_void_p(), C.c_size_t()
+        self._chk(self._L.qs_fused_counts(self._h, C.byref(p), C.byref(b)), "qs_fused_counts")
+        return p.value, b.value
+
+    def counts_source(self, fused):
+        self._chk(self._L.qs_counts_source(self._h, int(bool(fused))), "qs_counts_source")
+
+    def epoch_would_rebase(self, n, seq0=None):
+        w = C.c_int32()
+        self._chk(self._L.qs_epoch_query(self._h, UINT64_MAX if seq0 is None else int(seq0), n, C.byref(w)), "qs_epoch_query")
+        return bool(w.value)
+
+    def mark_fused(self):
+        self._chk(self._L.qs_mark_fused(self._h), "qs_mark_fused")
 
     def grid_to_pcd(self, grid, res, ox, oy):
         """MapMerger.grid_to_pcd (map_merger.py:64-85) -> float64 [n,2] (x, y)."""

@@ -39,24 +39,27 @@ def cycle_stream(pkts, n):
     return np.ascontiguousarray(np.tile(pkts, (reps, 1))[:n])
 
 
-def multi_bot_stream(pkts, n_bots, n, pitch=8.0, tiles_per_row=25, origin=(-98.0, -98.0), lap_shift=37):
+def multi_bot_stream(pkts, n_bots, n, pitch=8.0, tiles_per_row=25, origin=(-98.0, -98.0), lap_shift=37, tile0=0,
+                     agent0=1):
     """configs C3/C4 (build-defined; the reference has no >2-bot generator): bot i (agent id
-    i+1) lives in its own room tile on a `pitch`-metre lattice and replays the session's bot-1
-    (even i) or bot-2 (odd i) packets, started `lap_shift*i` packets into the lap; streams are
-    interleaved round-robin, n packets in total."""
+    agent0+i) lives in its own room tile (lattice position tile0+i: rank r of a sharded deployment passes
+    tile0 = r*n_bots, so the 512 bots of configs[3] occupy 512 different tiles of the 25 x 25 lattice) on a
+    `pitch`-metre lattice and replays the session's bot-1 (even i) or bot-2 (odd i) packets, started
+    `lap_shift*(tile0+i)` packets into the lap; streams are interleaved round-robin, n packets in total."""
     rec = pkts.view(P.PACKET_DTYPE).reshape(-1)
     lanes = [rec[rec["agent"] == 1], rec[rec["agent"] == 2]]
     per_bot = -(-n // n_bots)
     out = np.zeros((per_bot, n_bots), dtype=P.PACKET_DTYPE)
     for i in range(n_bots):
         src = lanes[i & 1]
-        idx = (np.arange(per_bot) + lap_shift * i) % len(src)
+        t = tile0 + i
+        idx = (np.arange(per_bot) + lap_shift * t) % len(src)
         r = src[idx].copy()
-        tx = origin[0] + pitch * (i % tiles_per_row)
-        ty = origin[1] + pitch * (i // tiles_per_row)
+        tx = origin[0] + pitch * (t % tiles_per_row)
+        ty = origin[1] + pitch * (t // tiles_per_row)
         r["x"] = (r["x"].astype(np.float64) + tx).astype(np.float32)
         r["y"] = (r["y"].astype(np.float64) + ty).astype(np.float32)
-        r["agent"] = i + 1
+        r["agent"] = agent0 + i
         out[:, i] = r
     flat = out.reshape(-1)[:n]
     return np.ascontiguousarray(flat.view(np.uint8).reshape(n, P.PACKET_SIZE))

@@ -32,6 +32,7 @@ extern "C" {
 #define QS_E_NOMEM (-3)
 #define QS_E_RANGE (-4)    /* index (bot, graph, capacity) out of range */
 #define QS_E_NODEV (-5)    /* no usable GPU */
+#define QS_E_STATE (-6)    /* call not valid in the context's current state (text in qs_last_error) */
 
 /* wire formats: dual_bot_mapper.py:41-54 */
 #define QS_PACKET_SIZE 42     /* QuasarPacket v2 '<4sBfffiIffffB' */
@@ -58,7 +59,13 @@ typedef struct qs_config {
     int32_t raycast_mode;       /* 0 = auto, 1 = direct global atomics, 2 = LDS tile-binned */
     int32_t seq_stride;         /* arrival index of record i = seq0 + i*seq_stride (0 = 1); a rank of an
                                    N-way round-robin sharded stream uses seq0 = base + rank, stride N */
-    int32_t reserved[6];
+    int32_t shard_bots;         /* > 0: this context is shard `shard_rank` of a deployment that keeps ONE pose graph over all
+                                   bots (PoseGraphSLAM is global across bots, :275, :294-309): every shard ingests the whole
+                                   interleaved stream (decode + loop closure replicated, identical on all shards) but casts
+                                   rays, keeps zones and runs the EKF only for its own agents
+                                   shard_rank*shard_bots+1 .. (shard_rank+1)*shard_bots.  0 = the context owns every agent */
+    int32_t shard_rank;
+    int32_t reserved[4];
 } qs_config;
 
 /* reference constants (dual_bot_mapper.py:57-99) */
@@ -142,6 +149,25 @@ int qs_fuse(qs_ctx *dst, qs_ctx *const *srcs, size_t n);
 /* same over raw device buffers (e.g. peers' grids gathered by the caller) */
 int qs_fuse_buffers(qs_ctx *dst, const void *const *stamps_dev, const void *const *counts_dev,
                     size_t n);
+/* fuse of a RANGE of cells: dst cells [cell_offset, cell_offset + n_cells) <- fuse(dst, sources), every source pointer
+ * naming the source's first cell of that range (the receive buffers of a reduce-scatter: each rank folds its peers'
+ * copies of ITS slice, then the slices are all-gathered).  Either pointer array may be NULL (stamps only / counters
+ * only).  counts_into_fused != 0 adds into the snapshot of qs_fused_counts instead of the local counters. */
+int qs_fuse_buffers_range(qs_ctx *dst, const void *const *stamps_dev, const void *const *counts_dev,
+                          size_t n, size_t cell_offset, size_t n_cells, int32_t counts_into_fused);
+/* ---- sharded streams (one context per GPU, the shared grid of dual_bot_mapper.py:785 kept in N pieces) -------------
+ * The local counters hold this context's own writes only and are never the target of a collective: qs_fused_counts
+ * copies them into a second buffer (on the context's stream) and returns it; the caller sums THAT over the ranks, as
+ * often as it likes.  qs_counts_source(ctx, 1) makes qs_grid_counts / qs_grid_logodds read the fused snapshot. */
+int qs_fused_counts(qs_ctx *ctx, void **fused_dev, size_t *bytes);
+int qs_counts_source(qs_ctx *ctx, int32_t fused);
+/* Stamp epochs: ordinals are 30 bits, so a batch that would pass 2^28 arrival indices first rebases the grid (every
+ * written cell -> ordinal 1).  With seq_stride > 1 the shards must have exchanged their stamps (MAX all-reduce) since
+ * their last write before that happens, or two ranks' writes to one cell would tie: qs_epoch_query tells whether the
+ * next ingest (same seq0 / n) would rebase -- the answer is the same on every rank --, qs_mark_fused records that the
+ * exchange has happened; an ingest that needs a rebase with unfused writes fails with QS_E_STATE. */
+int qs_epoch_query(qs_ctx *ctx, uint64_t seq0, size_t n, int32_t *would_rebase);
+int qs_mark_fused(qs_ctx *ctx);
 /* MapMerger.grid_to_pcd  server_nodes/map_merger.py:64-85: cells > 50 -> (col*res+ox,
  * row*res+oy) in row-major order.  grid: host int8 [h][w]; returns the count in *n_out. */
 int qs_grid_to_pcd(qs_ctx *ctx, const int8_t *grid, int32_t h, int32_t w, double res,
@@ -196,6 +222,9 @@ int qs_counters(qs_ctx *ctx, uint64_t out[QS_CNT_N]);
  * each stage of every ingest with events; qs_stage_times returns accumulated ms and the
  * launch count per stage since the last call with reset != 0. */
 enum { QS_STAGE_DECODE = 0, QS_STAGE_SLAM, QS_STAGE_RAYCAST, QS_STAGE_EKF,
+       /* single kernels inside the stages above (their time is part of the stage's too) */
+       QS_STAGE_SLAM_CHAIN,                     /* qs_slam_chain_kernel alone (inside SLAM) */
+       QS_STAGE_RC_RAYS, QS_STAGE_RC_SORT, QS_STAGE_RC_RASTER,   /* tiled raycast: pass A; passes B + C; pass D */
        QS_STAGE_N };
 int qs_timing_enable(qs_ctx *ctx, int32_t enable);
 int qs_stage_times(qs_ctx *ctx, double ms[QS_STAGE_N], uint64_t launches[QS_STAGE_N],

@@ -72,6 +72,9 @@ typedef struct {
     long n_rays, n_cells_written, n_datagrams;
     /* optional per-bot EKF on the build-defined telemetry wiring (see qso_ekf_packet) */
     int ekf_on; double ekf_mpt, cur_time; double *ekf, *ekf_prev;
+    /* build extension (qs_config.shard_bots): this mapper is one shard of a deployment that keeps ONE pose graph over
+     * all bots: it runs add_pose for every packet but casts rays / keeps zones / runs the EKF for agents own_lo..own_hi */
+    int own_lo, own_hi;
 } mapper_t;
 
 /* ---- OccupancyGrid ---------------------------------------------------------------- */
@@ -173,6 +176,7 @@ mapper_t *qso_create(int size, double res, double ox, double oy, double separati
     m->misses = calloc(cells, sizeof(int32_t));
     m->stamps = calloc(cells, sizeof(uint32_t));
     m->seq_stride = 1;
+    m->own_lo = 1; m->own_hi = m->max_agent;
     m->graphs = calloc(m->n_graphs, sizeof(graph_t));
     int nb = m->max_agent + 1;
     m->offset_x = calloc(nb, sizeof(double));
@@ -206,6 +210,7 @@ void qso_destroy(mapper_t *m)
 }
 
 void qso_set_offset(mapper_t *m, int bot, double off_x) { m->offset_x[bot] = off_x; }
+void qso_set_owned(mapper_t *m, int lo, int hi) { m->own_lo = lo; m->own_hi = hi; }
 
 void qso_ekf_packet(double *f, double *prev, double t, double x, double y, double yaw,
                     double enc, double metres_per_tick);
@@ -247,14 +252,15 @@ int qso_feed(mapper_t *m, const uint8_t *d, int len)
     if (!isfinite(rx) || !isfinite(ry) || !isfinite(ryaw)) return 0;
     m->pkt_count[agent]++;                               /* :848 */
     rx += m->offset_x[agent];  /* :851-852 (bot 2: separation; x + 0.0 is exact for the others) */
-    if (m->ekf_on) {   /* telemetry only: uses the pose before drift correction, never feeds the map */
+    const int owned = agent >= m->own_lo && agent <= m->own_hi;
+    if (m->ekf_on && owned) {   /* telemetry only: uses the pose before drift correction, never feeds the map */
         int32_t enc; memcpy(&enc, d + 17, 4);
         qso_ekf_packet(m->ekf + (size_t)agent * 44, m->ekf_prev + (size_t)agent * 4, m->cur_time, rx, ry, ryaw,
                        (double)enc, m->ekf_mpt);
     }
     rx += m->drift[2 * agent];                           /* :855-857 */
     ry += m->drift[2 * agent + 1];
-    zone_fold(m, agent, rx, ry);                         /* paths  :878-879 */
+    if (owned) zone_fold(m, agent, rx, ry);              /* paths  :878-879 */
     if (m->n_pose == m->cap_pose) {
         m->cap_pose = m->cap_pose ? 2 * m->cap_pose : 1024;
         m->pose = realloc(m->pose, 3 * m->cap_pose * sizeof(double));
@@ -263,7 +269,7 @@ int qso_feed(mapper_t *m, const uint8_t *d, int len)
     }
     m->pose[3 * m->n_pose] = rx; m->pose[3 * m->n_pose + 1] = ry; m->pose[3 * m->n_pose + 2] = ryaw;
     m->pose_agent[m->n_pose] = agent; m->pose_src[m->n_pose] = src; m->n_pose++;
-    for (int s = 0; s < 4; s++) {                        /* :886-903 */
+    for (int s = 0; s < 4 && owned; s++) {               /* :886-903 */
         m->cur_sensor = s;
         double a = ryaw + SENSOR_ANGLES_RAD[s];
         double dd = dist[s];

@@ -27,8 +27,7 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(_SO):
-            build()
+        build()                      # (re)compiles only when oracle.c is newer than the library
         L = C.CDLL(_SO)
         vp, i32, i64, f64 = C.c_void_p, C.c_int, C.c_long, C.c_double
         L.qso_create.restype = vp
@@ -36,6 +35,7 @@ def lib():
         L.qso_destroy.argtypes = [vp]
         L.qso_set_offset.argtypes = [vp, i32, f64]
         L.qso_set_closure_params.argtypes = [vp, f64, i64, f64]
+        L.qso_set_owned.argtypes = [vp, i32, i32]
         L.qso_feed.restype = i32
         L.qso_feed.argtypes = [vp, vp, i32]
         L.qso_feed_stream.restype = i64
@@ -109,6 +109,10 @@ class OracleMapper:
 
     def set_offset(self, bot, off_x):
         lib().qso_set_offset(self._h, bot, off_x)
+
+    def set_owned(self, lo, hi):
+        """One shard of a replicated-pose-graph deployment: add_pose for every packet, rays/zones/EKF for agents lo..hi."""
+        lib().qso_set_owned(self._h, lo, hi)
 
     def set_closure_params(self, radius=0.6, min_between=30, correction=0.5):
         """Other values of CLOSURE_RADIUS / MIN_POSES_BETWEEN / CLOSURE_CORRECTION (:99-101); before the first packet."""
