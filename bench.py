@@ -324,10 +324,10 @@ def replayed_traffic(profile_dir, kernels):
         path = os.path.join(ROOT, "profiles", "r02", profile_dir, fname)
         if not os.path.exists(path):
             return None
-        for line in open(path).read().splitlines()[1:]:
-            f = line.split(",")
-            if any(k in f[0] for k in kernels):
-                total += float(f[-1]) * 1024.0 * scale
+        import csv
+        for row in csv.DictReader(open(path, newline="")):
+            if any(k in row["kernel"] for k in kernels):
+                total += float(row["avg_KiB_per_dispatch"]) * 1024.0 * scale
                 found = True
     return total if found else None
 
@@ -380,6 +380,10 @@ def run_rank(args):
         dist.init_process_group(args.backend, rank=rank, world_size=world)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # one explicit HIP stream for everything: the library's kernels, torch's copies and events, and the stream RCCL's
+    # collectives order themselves against (torch's default stream has handle 0, which qs_set_stream reads as "own stream")
+    side = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(side)
 
     d_stream = torch.from_numpy(stream).to(dev)               # resident in HBM before timing
     d_time = torch.arange(B, dtype=torch.float64, device=dev) * 0.25
@@ -389,7 +393,8 @@ def run_rank(args):
                          enable_counts=counts, enable_ekf=bool(args.ekf), device=local_rank,
                          raycast_mode=args.raycast_mode, seq_stride=1 if replicated else world,
                          shard_bots=bots if replicated else 0, shard_rank=rank if replicated else 0)
-    m.set_stream(torch.cuda.current_stream().cuda_stream)
+    assert side.cuda_stream != 0
+    m.set_stream(side.cuda_stream)
     sm = distmod.ShardedMapper(m, dev, rank, world, mode="replicated" if replicated else "per_shard", fuse=args.fuse)
     sm.last_fused = None
 

@@ -386,7 +386,7 @@ def _replay(pkg):
 def test_full_size_properties_4096(pkg):
     """BASELINE configs[1] at full grid size (4096^2) and a 2^18-packet stream: properties that do
     not need the (quadratic) oracle over the whole stream -- the two raycast schedules agree bit for
-    bit, ragged batching is invisible, counters are consistent -- plus the oracle on a prefix."""
+    bit, ragged batching is invisible, counters are consistent -- and the oracle over the whole stream."""
     replay = _replay(pkg)
     session, _ = replay.telemetry_csv_to_packets()
     B = 1 << 18
@@ -412,8 +412,8 @@ def test_full_size_properties_4096(pkg):
                 break
         assert (t.grid_i8() == gt).all() and (t.counts()[0] == ht).all()
         assert (t.closures(0)[0] == d.closures(0)[0]).all()
-    # oracle on a prefix (its landmark scan is O(L) per event)
-    n = 40000
+    # the oracle over the whole 2^18-packet stream (~1 s in C)
+    n = B
     o = orc.OracleMapper(4096, 0.05, -102.4, -102.4, 0.0)
     o.feed_stream(stream[:n])
     with pkg.QuasarMapper(**kw) as m:
@@ -828,3 +828,183 @@ def test_raster_long_runs_flush_and_tile_changes(pkg):
     env = dict(os.environ, QS_RASTER_WGS="4")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+
+
+# ---- round 2: the N > 1 path emulated on one GPU (two HIP contexts = two ranks) ------------------------------------------
+def _exchange_stamps(a, b):
+    """What the MAX all-reduce leaves on both ranks, through the K3 kernel on raw device buffers."""
+    sa, _, _, _ = a.device_buffers(); sb_, _, _, _ = b.device_buffers()
+    a.sync(); b.sync()
+    a.fuse_buffers([sb_], None); a.sync()
+    b.fuse_buffers([sa], None); b.sync()
+    a.mark_fused(); b.mark_fused()
+
+
+def _sum_counter_snapshots(a, b, cells):
+    """What the SUM all-reduce of the counter SNAPSHOTS leaves on both ranks."""
+    a.sync(); b.sync()
+    fa, _ = a.fused_counts(); fb, _ = b.fused_counts()
+    a.sync(); b.sync()
+    _, _, ca, _ = a.device_buffers(); _, _, cb, _ = b.device_buffers()
+    a.fuse_buffers_range(None, [cb], 0, cells, counts_into_fused=True); a.sync()
+    b.fuse_buffers_range(None, [ca], 0, cells, counts_into_fused=True); b.sync()
+    a.counts_source(True); b.counts_source(True)
+
+
+def test_two_contexts_as_two_ranks_across_an_epoch_boundary(pkg):
+    """two HIP contexts drive the sharded path as two ranks (seq_stride = 2, seq0 = base + rank),
+    three batches with NO reset, the stream crossing the 2^28 stamp-epoch boundary between the second and the third.
+    Before the batch that rebases, the ranks exchange their stamps (dist.ShardedMapper does it when qs_epoch_query says
+    so; here by hand through qs_fuse_buffers) -- an ingest that would rebase with unfused writes is refused.  After every
+    batch the fused grid and the sum of the counter snapshots equal one mapper fed the interleaved stream, and the oracle."""
+    g = load("laps5_512")
+    pk = g["datagrams"][:, :42]
+    b1, b2 = pk[pk[:, 4] == 1], pk[pk[:, 4] == 2]
+    n = min(len(b1), len(b2)) // 3 * 3
+    b1, b2 = b1[:n], b2[:n].copy()
+    inter = np.empty((2 * n, 42), dtype=np.uint8); inter[0::2], inter[1::2] = b1, b2
+    b2[:, 4] = 1                                     # on its own rank's wire the bot is agent 1
+    kw = dict(size=512, resolution=0.05, origin_x=-12.8, origin_y=-12.8)
+    cells = 512 * 512
+    third = n // 3
+    base = (1 << 28) - 2 - 2 * 2 * third - 40        # batches 1 and 2 fit the first epoch, batch 3 does not
+    o = orc.OracleMapper(512, 0.05, -12.8, -12.8, 0.0, max_agent=2, bots_per_graph=1)
+    with pkg.QuasarMapper(max_agent=2, bots_per_graph=1, **kw) as ref, \
+         pkg.QuasarMapper(max_agent=1, seq_stride=2, **kw) as a, \
+         pkg.QuasarMapper(max_agent=1, seq_stride=2, **kw) as b:
+        for k in range(3):
+            lo, hi = k * third, (k + 1) * third
+            seq = base + 2 * lo
+            assert a.epoch_would_rebase(third, seq) == b.epoch_would_rebase(third, seq + 1) == (k == 2)
+            if k == 2:
+                _exchange_stamps(a, b)                               # (a no-op here: nothing was written since the last one)
+            a.ingest_array(b1[lo:hi], seq0=seq)
+            b.ingest_array(b2[lo:hi], seq0=seq + 1)
+            ref.ingest_array(inter[2 * lo:2 * hi], seq0=seq)
+            o.feed_stream(inter[2 * lo:2 * hi])
+            _exchange_stamps(a, b)
+            _sum_counter_snapshots(a, b, cells)
+            ga, gb = a.grid_i8(), b.grid_i8()
+            assert (ga == o.grid).all() and (gb == o.grid).all() and (ref.grid_i8() == o.grid).all(), f"batch {k}"
+            for m in (a, b):
+                h, mi = m.counts()                                    # fused view: global sums, no double counting
+                assert (h == o.hits).all() and (mi == o.misses).all(), f"batch {k}"
+        assert a.counters()["rebases"] == 1 and b.counters()["rebases"] == 1 and ref.counters()["rebases"] == 1
+        for gr, m in ((0, a), (1, b)):
+            assert (m.closures(0)[0] == o.closures(gr)[0]).all() and (ref.closures(gr)[0] == o.closures(gr)[0]).all()
+        # a shard with writes its peers have not seen must not rebase: the ingest is refused (QS_E_STATE), nothing is lost
+        a.ingest_array(b1[:10], seq0=base + 6 * third + 100)
+        with pytest.raises(pkg.QuasarError, match="crosses a stamp epoch"):
+            a.ingest_array(b1[:10], seq0=(1 << 29) + 1000)
+        a.mark_fused()
+        a.ingest_array(b1[:10], seq0=(1 << 29) + 1000)
+        assert a.counters()["rebases"] == 2
+        a.counts_source(False)
+        h_local, _ = a.counts()
+        assert int(h_local.sum()) < int(o.hits.sum())                 # the local counters still hold rank 0's writes only
+
+
+def test_replicated_pose_graph_two_contexts(pkg):
+    """VERDICT r1 item 8 (replicated mode): ONE pose graph over all bots -- node indices global across
+    bots (:275), cross-bot matches allowed (:294-309) -- with the map sharded by agent.  Every rank ingests the whole
+    interleaved stream (decode + chain replicated) and casts rays only for its own agent (shard_bots = 1); fused grid,
+    closures, drift = one mapper with one pose graph = the oracle = the reference's semantics."""
+    g = load("laps5_512")
+    inter = g["datagrams"][:, :42]
+    kw = dict(size=512, resolution=0.05, origin_x=-12.8, origin_y=-12.8, max_agent=2, bots_per_graph=0)
+    o = orc.OracleMapper(512, 0.05, -12.8, -12.8, 0.0)
+    o.feed_stream(inter)
+    with pkg.QuasarMapper(shard_bots=1, shard_rank=0, enable_ekf=True, **kw) as a, \
+         pkg.QuasarMapper(shard_bots=1, shard_rank=1, enable_ekf=True, **kw) as b:
+        half = len(inter) // 2
+        for lo, hi in ((0, half), (half, len(inter))):
+            a.ingest_array(inter[lo:hi]); b.ingest_array(inter[lo:hi])
+        oi, oc = o.closures(0)
+        assert len(oi) > 20
+        for m in (a, b):                                              # the replicated chain: identical everywhere
+            idx, corr = m.closures(0)
+            assert (idx == oi).all() and np.abs(corr - oc).max() < FLOAT_TOL
+            for bot in (1, 2):
+                assert np.abs(m.drift(bot) - o.drift(bot)).max() < FLOAT_TOL
+        ga = a.grid_i8()
+        assert not (ga == o.grid).all()                               # a shard alone holds only its agent's rays
+        _exchange_stamps(a, b)
+        _sum_counter_snapshots(a, b, 512 * 512)
+        assert (a.grid_i8() == o.grid).all() and (b.grid_i8() == o.grid).all()
+        h, mi = a.counts()
+        assert (h == o.hits).all() and (mi == o.misses).all()
+        # zones and rays belong to the owner only
+        assert a.zone(2) is None and b.zone(1) is None
+        assert np.abs(np.array(a.zone(1)) - o.zone(1)).max() < FLOAT_TOL and np.abs(np.array(b.zone(2)) - o.zone(2)).max() < FLOAT_TOL
+        ca, cb = a.counters(), b.counters()
+        assert ca["rays"] + cb["rays"] == o.n_rays and ca["cells"] + cb["cells"] == o.n_cells_written
+        acc, _ = a.last_batch()
+        assert acc.all()                                              # accepted = part of the pose graph, owned or not
+
+
+def test_sharded_mapper_wrapper_single_rank_nccl(pkg):
+    """dist.ShardedMapper end to end on one GPU (RCCL, world_size 1): ingest -> fuse (both algorithms) -> repeated fuse
+    without reset leaves the counters alone (an in-place SUM all-reduce doubled them)."""
+    import importlib
+    import torch
+    import torch.distributed as dist
+    distmod = importlib.import_module(pkg.__name__ + ".dist")
+    g = load("session_512")
+    dev = torch.device("cuda", 0)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ["MASTER_PORT"] = "29578"
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        side = torch.cuda.Stream(device=dev)          # (torch's default stream has handle 0 = "own stream" to qs_set_stream)
+        torch.cuda.set_stream(side)
+        for algo in ("allreduce", "direct"):
+            with make_mapper(pkg, g) as m:
+                m.set_stream(side.cuda_stream)
+                sm = distmod.ShardedMapper(m, dev, 0, 1, fuse=algo)
+                d = torch.from_numpy(np.ascontiguousarray(g["datagrams"][:, :42])).to(dev)
+                ok = g["lengths"] == 42
+                assert ok.all()
+                sm.ingest(d[:300], None, seq_base=0)
+                distmod.allreduce_grids(m, dev, algo=algo, sync=False)
+                sm.ingest(d[300:], None, seq_base=300)
+                distmod.allreduce_grids(m, dev, algo=algo, sync=False)
+                distmod.allreduce_grids(m, dev, algo=algo, sync=False)
+                torch.cuda.synchronize()
+                assert hashlib.sha256(m.grid_i8().tobytes()).digest() == g["grid_sha256"].tobytes()
+                o = orc.OracleMapper(512, 0.05, -12.8, -12.8, 0.0); o.feed_stream(g["datagrams"], g["lengths"])
+                h, mi = m.counts()
+                assert (h == o.hits).all() and (mi == o.misses).all()
+    finally:
+        torch.cuda.set_stream(torch.cuda.default_stream(dev))
+        dist.destroy_process_group()
+
+
+def test_fuse_kernel_many_sources_and_ranges(pkg):
+    """K3 with 1..70 sources (unrolled groups of 8 + a partial group + a second launch past 64) and on cell ranges,
+    against numpy."""
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(5)
+    with pkg.QuasarMapper(256, 0.05, -6.4, -6.4) as m:
+        cells = 256 * 256
+        for G in (1, 7, 8, 9, 33, 64, 70):
+            m.reset(); m.sync()
+            st = rng.integers(0, 1 << 30, (G, cells)).astype(np.int32)
+            ct = rng.integers(0, 1 << 16, (G, cells, 2)).astype(np.int32)
+            d_st = torch.from_numpy(st).to(dev); d_ct = torch.from_numpy(ct).to(dev)
+            m.fuse_buffers([d_st[k].data_ptr() for k in range(G)], [d_ct[k].data_ptr() for k in range(G)])
+            m.sync()
+            stamps = st.max(axis=0)
+            exp = np.where(stamps == 0, -1, np.where(stamps & 1, 100, 0)).astype(np.int8).reshape(256, 256)
+            assert (m.grid_i8() == exp).all(), G
+            h, mi = m.counts()
+            assert (h.reshape(-1) == ct[:, :, 1].sum(axis=0)).all() and (mi.reshape(-1) == ct[:, :, 0].sum(axis=0)).all(), G
+        # a range: only cells [off, off + n) change
+        m.reset(); m.sync()
+        off, n = 1024, 4096
+        src = torch.from_numpy(rng.integers(2, 1 << 20, (3, n)).astype(np.int32)).to(dev)
+        m.fuse_buffers_range([src[k].data_ptr() for k in range(3)], None, off, n)
+        m.sync()
+        gi = m.grid_i8().reshape(-1)
+        assert (gi[:off] == -1).all() and (gi[off + n:] == -1).all() and (gi[off:off + n] != -1).all()
+        with pytest.raises(pkg.QuasarError):
+            m.fuse_buffers_range([src[0].data_ptr()], None, 2, 4)        # ranges are multiples of 4 cells
