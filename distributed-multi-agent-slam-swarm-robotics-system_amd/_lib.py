@@ -102,6 +102,8 @@ SIGNATURES = {
     "qs_grid_to_pcd": (_i32, [_vp, _vp, _i32, _i32, _f64, _f64, _f64, _vp, _sz, C.POINTER(_sz)]),
     "qs_rasterise": (_i32, [_vp, _vp, _sz, _f64, _vp, _vp, _vp]),
     "qs_icp": (_i32, [_vp, _vp, _sz, _vp, _sz, _f64, _i32, _f64, _f64, _vp, _vp, _vp, _vp]),
+    "qs_nn_search": (_i32, [_vp, _vp, _sz, _vp, _sz, _f64, _i32, _vp, _vp, _vp]),
+    "qs_diag_mfma_f64_rate": (_i32, [_vp, C.POINTER(_f64)]),
     "qs_voxel_downsample": (_i32, [_vp, _vp, _sz, _f64, _vp, _sz, C.POINTER(_sz)]),
     "qs_frontier_cells": (_i32, [_vp, _vp, _sz, C.POINTER(_sz)]),
     "qs_frontier_clusters": (_i32, [_vp, _i32, _vp, _sz, C.POINTER(_sz)]),

@@ -47,6 +47,178 @@ qs_icp_nn_kernel(const double2 *__restrict__ src, size_t n_src, const double2 *_
     }
 }
 
+// ---- the same search with the distance matrix on the matrix cores ------------------------------------------
+// The source x target squared-distance matrix is the one dense contraction of this code base:
+//     d2(i, j) = |s_i|^2 + ( |t_j|^2 - 2 s_i . t_j )  =  |s_i|^2 + [sx, sy, 1, 0] . [-2 tx, -2 ty, |t|^2, 0]^T,
+// K = 4 exactly: one v_mfma_f64_16x16x4_f64 gives the bracket S(i, j) for 16 sources x 16 targets.  The matrix value
+// is a SCREEN, never the decision: it differs from the reference expression (dx*dx + dy*dy on the raw coordinates) by
+// rounding -- coordinates are centred to keep the cancellation small -- so every result slot (source row, target
+// column class) keeps the lowest S it has seen plus a margin (2^-40 (max |s'|^2 + max |t'|^2), ~40 times the worst-case
+// difference between S + |s'|^2 and the reference expression); an element at or under that threshold is re-evaluated
+// with the reference expression in fp64 and competes on (d2, target index).  The true nearest target always passes
+// (its S is within the margin of every other S of its row), so the result is the scalar kernel's, bit for bit, ties
+// included.
+// What makes it fast is keeping the screen tight and the re-evaluation off the matrix pipe's critical path:
+//   * one wave owns NNM_ROWT row tiles of 16 sources; a B fragment (16 targets) feeds NNM_ROWT MFMAs;
+//   * two accumulator sets: tile n + 1's products are on the matrix pipe while tile n's are screened on the VALU;
+//   * target chunks are visited in a strided order (a map's points come in raster order: in stream order the threshold
+//     would crawl towards every source row and most tiles would take the re-evaluation path), and after every chunk the
+//     16 lanes of a source row share their lowest threshold: after the first chunks only genuine near-ties pass;
+//   * the re-evaluation reads raw coordinates from LDS (targets: staged with the operands; sources: 1 KiB per wave),
+//     so it is ~100 VALU cycles under MFMAs already in flight, not a global round trip.
+#define NNM_WAVES 2
+#define NNM_ROWT 4                           // 64 sources per wave
+#define NNM_CHUNK 512                        // targets per LDS stage: 5 planes x 4 KiB (4 workgroups per CU: the VGPR limit)
+typedef double qs_d4 __attribute__((ext_vector_type(4)));
+
+// planes[k][j], k = 0..2: -2 tx', -2 ty', |t'|^2 for target j (centred); padding columns: |t'|^2 = +inf
+__global__ void __launch_bounds__(ICP_BLOCK)
+qs_icp_prep_kernel(const double2 *__restrict__ dst, size_t n_dst, size_t n_pad, double cx, double cy, double *__restrict__ planes)
+{
+    const size_t j = (size_t)blockIdx.x * ICP_BLOCK + threadIdx.x;
+    if (j >= n_pad) return;
+    double a = 0, b = 0, c = INFINITY;
+    if (j < n_dst) {
+        const double tx = dst[j].x - cx, ty = dst[j].y - cy;
+        a = -2.0 * tx; b = -2.0 * ty; c = tx * tx + ty * ty;
+    }
+    planes[j] = a; planes[n_pad + j] = b; planes[2 * n_pad + j] = c;
+}
+
+struct NnmState { double thr[NNM_ROWT][4], best[NNM_ROWT][4]; int best_j[NNM_ROWT][4]; };
+// what passed the screen (mk: the wave's pass mask per result slot) is re-evaluated exactly -- raw coordinates from
+// LDS -- and competes on (d2, target index)
+__device__ inline void nnm_recheck(const qs_d4 (&d)[NNM_ROWT], const unsigned long long (&mk)[NNM_ROWT][4], NnmState &st, int j,
+                                   double mrg, double tx, double ty, const double2 *s_src_lk)
+{
+    #pragma unroll
+    for (int t = 0; t < NNM_ROWT; t++)
+        #pragma unroll
+        for (int r = 0; r < 4; r++) {
+            if (mk[t][r] == 0) continue;                                           // (uniform)
+            const double S = d[t][r];
+            if (S <= st.thr[t][r]) {
+                const double nt = S + mrg;
+                st.thr[t][r] = nt < st.thr[t][r] ? nt : st.thr[t][r];
+                const double2 p = s_src_lk[16 * t + 4 * r];
+                const double dx = p.x - tx, dy = p.y - ty;                         // the reference expression
+                const double d2 = dx * dx + dy * dy;
+                if (d2 < st.best[t][r] || (d2 == st.best[t][r] && j < st.best_j[t][r])) { st.best[t][r] = d2; st.best_j[t][r] = j; }
+            }
+        }
+}
+// One step: the NNM_ROWT MFMAs of the NEXT target tile (operand `bop`) are issued one by one, each followed by the
+// compares of a quarter of the CURRENT tile's products with their thresholds: 16 v_cmp_le_f64 into scalar masks and 16
+// scalar ORs are the whole screen (fp64 compares run on the units the fp64 MFMA runs on -- MI355X's fp64 matrix rate IS
+// its fp64 vector rate -- so every compare saved is matrix time).
+#define NNM_STEP(dnew, dold, bop, mk, anym)                                                                    \
+    _Pragma("unroll") for (int t = 0; t < NNM_ROWT; t++) {                                                      \
+        dnew[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_op[t], bop, zero, 0, 0, 0);                            \
+        _Pragma("unroll") for (int r = 0; r < 4; r++) { mk[t][r] = __ballot(dold[t][r] <= st.thr[t][r]); anym |= mk[t][r]; } \
+    }
+
+__global__ void __launch_bounds__(NNM_WAVES * QS_WAVE)
+qs_icp_nn_mfma_kernel(const double2 *__restrict__ src, size_t n_src, const double2 *__restrict__ dst, size_t n_dst,
+                      const double *__restrict__ planes, size_t n_pad, double cx, double cy, double t2max, double max_d2,
+                      unsigned int chunk_step, int *__restrict__ corr, double *__restrict__ d2_out)
+{
+    __shared__ double s_b[3][NNM_CHUNK];                 // operand planes of the chunk
+    __shared__ double s_tx[NNM_CHUNK], s_ty[NNM_CHUNK];  // its raw coordinates (re-evaluation)
+    __shared__ double2 s_src[NNM_WAVES][16 * NNM_ROWT];  // the wave's raw source coordinates
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lc = lane & 15, lk = lane >> 4;
+    const size_t row0 = ((size_t)blockIdx.x * NNM_WAVES + wave) * (16 * NNM_ROWT);
+
+    double a_op[NNM_ROWT];                       // A fragment: A[row = lane & 15][k = lane >> 4]
+    NnmState st;                                 // per result slot: row = row0 + 16 t + (lane >> 4) + 4 r, column class lane & 15
+    double s2 = 0.0;
+    #pragma unroll
+    for (int t = 0; t < NNM_ROWT; t++) {
+        const size_t ra = row0 + 16 * t + lc;
+        const double2 pa = ra < n_src ? src[ra] : make_double2(cx, cy);
+        if (lk == 0) s_src[wave][16 * t + lc] = pa;
+        const double ux = pa.x - cx, uy = pa.y - cy;
+        a_op[t] = lk == 0 ? ux : (lk == 1 ? uy : (lk == 2 ? 1.0 : 0.0));
+        const double u2 = ux * ux + uy * uy;
+        s2 = (u2 > s2) ? u2 : s2;                // (NaN rows: never larger; their S is NaN and never passes)
+        #pragma unroll
+        for (int r = 0; r < 4; r++) { st.thr[t][r] = INFINITY; st.best[t][r] = INFINITY; st.best_j[t][r] = 0x7fffffff; }
+    }
+    #pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(s2, off); s2 = o > s2 ? o : s2; }
+    const double mrg = (s2 + t2max) * 0x1p-40;   // one margin for the wave's 64 rows: the largest of theirs
+    const qs_d4 zero = {0.0, 0.0, 0.0, 0.0};
+    const double2 *const s_src_lk = &s_src[wave][lk];
+    const int pk = lk < 3 ? lk : 0;              // lanes of k = 3 multiply by A = 0: any finite B would do; they read plane 0 ...
+
+    const unsigned int n_chunks = (unsigned int)((n_pad + NNM_CHUNK - 1) / NNM_CHUNK);
+    unsigned int ci = 0;
+    for (unsigned int it = 0; it < n_chunks; it++, ci = (ci + chunk_step) % n_chunks) {
+        const size_t base = (size_t)ci * NNM_CHUNK;
+        const size_t cnt = (n_pad - base < NNM_CHUNK) ? n_pad - base : NNM_CHUNK;      // a multiple of 16
+        __syncthreads();
+        for (size_t j = tid; j < cnt; j += NNM_WAVES * QS_WAVE) {
+            s_b[0][j] = planes[base + j]; s_b[1][j] = planes[n_pad + base + j]; s_b[2][j] = planes[2 * n_pad + base + j];
+            const double2 tp = base + j < n_dst ? dst[base + j] : make_double2(INFINITY, INFINITY);
+            s_tx[j] = tp.x; s_ty[j] = tp.y;
+        }
+        __syncthreads();
+        const int tiles = (int)(cnt / 16);
+        // two accumulator sets (no copies), B operands read from LDS one step ahead of their MFMAs
+        qs_d4 dA[NNM_ROWT], dB[NNM_ROWT];
+        double b_cur = s_b[pk][lc];
+        b_cur = lk < 3 ? b_cur : 0.0;            // ... and turn it into the operand's zero row (-2 tx' may be inf / NaN)
+        double b_nxt = tiles > 1 ? s_b[pk][16 + lc] : 0.0;
+        #pragma unroll
+        for (int t = 0; t < NNM_ROWT; t++) dA[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_op[t], b_cur, zero, 0, 0, 0);
+        for (int tile = 0; tile < tiles; tile += 2) {
+            // dA = tile, issue tile + 1 into dB
+            b_cur = lk < 3 ? b_nxt : 0.0;
+            if (tile + 2 < tiles) b_nxt = s_b[pk][16 * (tile + 2) + lc];
+            unsigned long long mk[NNM_ROWT][4], anym = 0;     // (past the last tile the MFMAs run on a stale operand; nobody looks)
+            const bool i1 = tile + 1 < tiles;
+            NNM_STEP(dB, dA, b_cur, mk, anym)
+            if (anym) nnm_recheck(dA, mk, st, (int)(base + 16 * (size_t)tile + lc), mrg, s_tx[16 * tile + lc], s_ty[16 * tile + lc], s_src_lk);
+            if (!i1) break;
+            // dB = tile + 1, issue tile + 2 into dA
+            b_cur = lk < 3 ? b_nxt : 0.0;
+            if (tile + 3 < tiles) b_nxt = s_b[pk][16 * (tile + 3) + lc];
+            anym = 0;
+            NNM_STEP(dA, dB, b_cur, mk, anym)
+            if (anym) nnm_recheck(dB, mk, st, (int)(base + 16 * (size_t)(tile + 1) + lc), mrg, s_tx[16 * (tile + 1) + lc], s_ty[16 * (tile + 1) + lc], s_src_lk);
+        }
+        // the 16 lanes of a source row (same lane >> 4) share their lowest threshold
+        #pragma unroll
+        for (int t = 0; t < NNM_ROWT; t++)
+            #pragma unroll
+            for (int r = 0; r < 4; r++) {
+                double v = st.thr[t][r];
+                #pragma unroll
+                for (int off = 8; off > 0; off >>= 1) { const double o = __shfl_xor(v, off); v = o < v ? o : v; }
+                st.thr[t][r] = v;
+            }
+    }
+    // the 16 lanes that hold one source row: lexicographic minimum of (d2, j)
+    #pragma unroll
+    for (int t = 0; t < NNM_ROWT; t++)
+        #pragma unroll
+        for (int r = 0; r < 4; r++) {
+            double b = st.best[t][r]; int bj = st.best_j[t][r];
+            #pragma unroll
+            for (int off = 8; off > 0; off >>= 1) {
+                const double ob = __shfl_xor(b, off); const int oj = __shfl_xor(bj, off);
+                const bool take = ob < b || (ob == b && oj < bj);
+                b = take ? ob : b; bj = take ? oj : bj;
+            }
+            const size_t rr = row0 + lk + 16 * t + 4 * r;
+            if (lc == 0 && rr < n_src) {
+                const bool ok = bj != 0x7fffffff && b < max_d2;
+                corr[rr] = ok ? bj : -1;
+                d2_out[rr] = ok ? b : 0.0;
+            }
+        }
+}
+
 // ---- fixed-order two-level sums ---------------------------------------------------------------------
 // pass 0: per block {n, sum d2, sum ax, sum ay, sum bx, sum by}; pass 1 (means known):
 // {sum (ax-am)(bx-bm) + (ay..)(by..), sum (ax-am)(by-bm) - (ay-am)(bx-bm)}
@@ -120,6 +292,53 @@ hipError_t qs_launch_icp_nn(qs_ctx *c, const double2 *src, size_t n_src, const d
 {
     hipLaunchKernelGGL(qs_icp_nn_kernel, dim3((unsigned int)((n_src + ICP_BLOCK - 1) / ICP_BLOCK)), dim3(ICP_BLOCK), 0,
                        c->stream, src, n_src, dst, n_dst, max_d2, corr, d2);
+    return hipGetLastError();
+}
+
+// ---- diagnostic: the chip's fp64 MFMA issue rate (what the search above is priced against) -----------------
+// every wave issues `iters` x 4 independent v_mfma_f64_16x16x4_f64 back to back; operands in registers
+__global__ void __launch_bounds__(256)
+qs_mfma_f64_rate_kernel(int iters, double *__restrict__ sink)
+{
+    qs_d4 acc[4];
+    #pragma unroll
+    for (int q = 0; q < 4; q++) acc[q] = qs_d4{0.0, 0.0, 0.0, 0.0};
+    const double a = 1.0 + threadIdx.x * 1e-3, b = 0.5 - threadIdx.x * 1e-3;
+    for (int it = 0; it < iters; it++) {
+        #pragma unroll
+        for (int q = 0; q < 4; q++) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[q], 0, 0, 0);
+    }
+    double v = 0;
+    #pragma unroll
+    for (int q = 0; q < 4; q++) v += acc[q][0] + acc[q][1] + acc[q][2] + acc[q][3];
+    if (v == 123.456) sink[0] = v;          // keeps the chain alive
+}
+hipError_t qs_launch_mfma_f64_rate(qs_ctx *c, int blocks, int iters, double *sink)
+{
+    hipLaunchKernelGGL(qs_mfma_f64_rate_kernel, dim3(blocks), dim3(256), 0, c->stream, iters, sink);
+    return hipGetLastError();
+}
+
+hipError_t qs_launch_icp_prep(qs_ctx *c, const double2 *dst, size_t n_dst, size_t n_pad, double cx, double cy, double *planes)
+{
+    hipLaunchKernelGGL(qs_icp_prep_kernel, dim3((unsigned int)((n_pad + ICP_BLOCK - 1) / ICP_BLOCK)), dim3(ICP_BLOCK), 0, c->stream,
+                       dst, n_dst, n_pad, cx, cy, planes);
+    return hipGetLastError();
+}
+
+hipError_t qs_launch_icp_nn_mfma(qs_ctx *c, const double2 *src, size_t n_src, const double2 *dst, size_t n_dst,
+                                 const double *planes, size_t n_pad, double cx, double cy, double t2max, double max_d2,
+                                 int *corr, double *d2)
+{
+    const size_t rows_per_wg = (size_t)NNM_WAVES * 16 * NNM_ROWT;
+    // chunk visiting order: steps of ~0.618 n_chunks, coprime with n_chunks (every chunk exactly once)
+    const unsigned int n_chunks = (unsigned int)((n_pad + NNM_CHUNK - 1) / NNM_CHUNK);
+    unsigned int step = (unsigned int)(0.6180339887 * n_chunks);
+    if (step < 1) step = 1;
+    auto gcd = [](unsigned int a, unsigned int b) { while (b) { const unsigned int t = a % b; a = b; b = t; } return a; };
+    while (gcd(step, n_chunks) != 1) step++;
+    hipLaunchKernelGGL(qs_icp_nn_mfma_kernel, dim3((unsigned int)((n_src + rows_per_wg - 1) / rows_per_wg)), dim3(NNM_WAVES * QS_WAVE),
+                       0, c->stream, src, n_src, dst, n_dst, planes, n_pad, cx, cy, t2max, max_d2, step % n_chunks, corr, d2);
     return hipGetLastError();
 }
 

@@ -1022,6 +1022,74 @@ extern "C" int qs_rasterise(qs_ctx *c, const double *xy, size_t n, double res, i
 }
 
 // ---- ICP / voxel down-sample (map_merger.py:45-60; Open3D semantics, parity unpinned) ------------------
+// The correspondence search (nearest target of every source point) has two implementations with identical results:
+// the scalar fp64 brute force and the MFMA-screened one (icp.hip).  mode 0 = auto (MFMA from 64 targets up).
+struct NnPlan { double cx, cy, t2max; size_t n_pad; double *planes; bool mfma; };
+
+static hipError_t nn_prepare(qs_ctx *c, const double *dst_xy, size_t n_dst, const double2 *d_dst, int mode, NnPlan &pl)
+{
+    pl = NnPlan{0, 0, 0, 0, nullptr, false};
+    pl.mfma = mode == 2 || (mode == 0 && n_dst >= 64);
+    if (!pl.mfma) return hipSuccess;
+    double mnx = INFINITY, mny = INFINITY, mxx = -INFINITY, mxy = -INFINITY;
+    for (size_t j = 0; j < n_dst; j++) {
+        const double x = dst_xy[2 * j], y = dst_xy[2 * j + 1];
+        if (isfinite(x)) { mnx = x < mnx ? x : mnx; mxx = x > mxx ? x : mxx; }
+        if (isfinite(y)) { mny = y < mny ? y : mny; mxy = y > mxy ? y : mxy; }
+    }
+    pl.cx = isfinite(mnx) ? 0.5 * (mnx + mxx) : 0.0; pl.cy = isfinite(mny) ? 0.5 * (mny + mxy) : 0.0;
+    const double hx = isfinite(mnx) ? mxx - pl.cx : 0.0, hy = isfinite(mny) ? mxy - pl.cy : 0.0;
+    pl.t2max = 1.0001 * (hx * hx + hy * hy) + 1e-300;          // >= every finite target's centred squared norm
+    pl.n_pad = (n_dst + 15) / 16 * 16;
+    hipError_t e = hipMalloc((void **)&pl.planes, 3 * pl.n_pad * sizeof(double));
+    if (e == hipSuccess) e = qs_launch_icp_prep(c, d_dst, n_dst, pl.n_pad, pl.cx, pl.cy, pl.planes);
+    return e;
+}
+
+static hipError_t nn_run(qs_ctx *c, const NnPlan &pl, const double2 *d_src, size_t n_src, const double2 *d_dst, size_t n_dst,
+                         double max_d2, int *d_corr, double *d_d2)
+{
+    if (pl.mfma) return qs_launch_icp_nn_mfma(c, d_src, n_src, d_dst, n_dst, pl.planes, pl.n_pad, pl.cx, pl.cy, pl.t2max, max_d2, d_corr, d_d2);
+    return qs_launch_icp_nn(c, d_src, n_src, d_dst, n_dst, max_d2, d_corr, d_d2);
+}
+
+// Build extension (the correspondence step of registration_icp on its own; used by the tests and tools/bench_icp_nn.py):
+// corr[i] = index of the target nearest to source i if closer than max_dist, else -1 (ties: lowest index); d2[i] its squared
+// distance (0 without a correspondence).  ms (may be NULL): HIP-event time of {the search kernel, the operand preparation}.
+extern "C" int qs_nn_search(qs_ctx *c, const double *src_xy, size_t n_src, const double *dst_xy, size_t n_dst, double max_dist,
+                            int32_t mode, int32_t *corr, double *d2, float ms[2])
+{
+    ARGCHK(c, c != nullptr && corr != nullptr && d2 != nullptr);
+    ARGCHK(c, n_src > 0 && n_dst > 0 && src_xy && dst_xy && max_dist > 0 && mode >= 0 && mode <= 2);
+    ARGCHK(c, n_dst < (size_t)1 << 31);
+    HIPCHK(c, hipSetDevice(c->device));
+    double2 *d_src = nullptr, *d_dst = nullptr; int *d_corr = nullptr; double *d_d2 = nullptr;
+    NnPlan pl{};
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipError_t e = hipMalloc((void **)&d_src, n_src * sizeof(double2));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_dst, n_dst * sizeof(double2));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_corr, n_src * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_d2, n_src * sizeof(double));
+    for (int k = 0; k < 4 && e == hipSuccess; k++) e = hipEventCreate(&ev[k]);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_src, src_xy, n_src * sizeof(double2), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_dst, dst_xy, n_dst * sizeof(double2), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipEventRecord(ev[0], c->stream);
+    if (e == hipSuccess) e = nn_prepare(c, dst_xy, n_dst, d_dst, mode, pl);
+    if (e == hipSuccess) e = hipEventRecord(ev[1], c->stream);
+    if (e == hipSuccess) e = nn_run(c, pl, d_src, n_src, d_dst, n_dst, max_dist * max_dist, d_corr, d_d2);      // warm (code load, caches)
+    if (e == hipSuccess) e = hipEventRecord(ev[2], c->stream);
+    if (e == hipSuccess) e = nn_run(c, pl, d_src, n_src, d_dst, n_dst, max_dist * max_dist, d_corr, d_d2);
+    if (e == hipSuccess) e = hipEventRecord(ev[3], c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(corr, d_corr, n_src * sizeof(int), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d2, d_d2, n_src * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess && ms) { hipEventElapsedTime(&ms[0], ev[2], ev[3]); hipEventElapsedTime(&ms[1], ev[0], ev[1]); }
+    for (int k = 0; k < 4; k++) if (ev[k]) hipEventDestroy(ev[k]);
+    hipFree(d_src); hipFree(d_dst); hipFree(d_corr); hipFree(d_d2); hipFree(pl.planes);
+    if (e != hipSuccess) return qs_fail(c, QS_E_HIP, "qs_nn_search", e);
+    return QS_OK;
+}
+
 extern "C" int qs_icp(qs_ctx *c, const double *src_xy, size_t n_src, const double *dst_xy, size_t n_dst, double max_dist,
                       int32_t max_iter, double rel_fitness, double rel_rmse, double T[9], double *fitness, double *rmse,
                       int32_t *iters)
@@ -1039,11 +1107,13 @@ extern "C" int qs_icp(qs_ctx *c, const double *src_xy, size_t n_src, const doubl
     if (e == hipSuccess) e = hipMalloc((void **)&d_out, 6 * sizeof(double));
     if (e == hipSuccess) e = hipMemcpyAsync(d_src, src_xy, n_src * sizeof(double2), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_dst, dst_xy, n_dst * sizeof(double2), hipMemcpyHostToDevice, c->stream);
+    NnPlan pl{};
+    if (e == hipSuccess) e = nn_prepare(c, dst_xy, n_dst, d_dst, 0, pl);     // the targets do not move: operands once per registration
     double tc = 1.0, ts = 0.0, tx = 0.0, ty = 0.0;          // accumulated transform
     double out[6] = {0};
     const double zero4[4] = {0, 0, 0, 0};
     auto evaluate = [&](double &fit, double &rm) -> hipError_t {
-        hipError_t ee = qs_launch_icp_nn(c, d_src, n_src, d_dst, n_dst, max_dist * max_dist, d_corr, d_d2);
+        hipError_t ee = nn_run(c, pl, d_src, n_src, d_dst, n_dst, max_dist * max_dist, d_corr, d_d2);
         if (ee == hipSuccess) ee = qs_launch_icp_sums(c, d_src, n_src, d_dst, d_corr, d_d2, 0, zero4, d_part, d_out);
         if (ee == hipSuccess) ee = hipMemcpyAsync(out, d_out, sizeof out, hipMemcpyDeviceToHost, c->stream);
         if (ee == hipSuccess) ee = hipStreamSynchronize(c->stream);
@@ -1078,11 +1148,38 @@ extern "C" int qs_icp(qs_ctx *c, const double *src_xy, size_t n_src, const doubl
         if (e == hipSuccess) e = evaluate(fit, rm);
         if (e == hipSuccess && fabs(bfit - fit) < rel_fitness && fabs(brm - rm) < rel_rmse) { it++; break; }
     }
-    hipFree(d_src); hipFree(d_dst); hipFree(d_corr); hipFree(d_d2); hipFree(d_part); hipFree(d_out);
+    hipFree(d_src); hipFree(d_dst); hipFree(d_corr); hipFree(d_d2); hipFree(d_part); hipFree(d_out); hipFree(pl.planes);
     if (e != hipSuccess) return qs_fail(c, QS_E_HIP, "qs_icp", e);
     T[0] = tc; T[1] = -ts; T[2] = tx; T[3] = ts; T[4] = tc; T[5] = ty; T[6] = 0; T[7] = 0; T[8] = 1;
     *fitness = fit; *rmse = rm;
     if (iters) *iters = it;
+    return QS_OK;
+}
+
+// Diagnostic: measured fp64 MFMA rate of this GPU (dense v_mfma_f64_16x16x4_f64, every CU, 2 waves per SIMD), TFLOP/s.
+extern "C" int qs_diag_mfma_f64_rate(qs_ctx *c, double *tflops)
+{
+    ARGCHK(c, c != nullptr && tflops != nullptr);
+    HIPCHK(c, hipSetDevice(c->device));
+    double *sink = nullptr;
+    hipEvent_t a = nullptr, b = nullptr;
+    const int blocks = 256 * 2, iters = 20000;             // 2 workgroups of 4 waves per CU
+    hipError_t e = hipMalloc((void **)&sink, 8);
+    if (e == hipSuccess) e = hipEventCreate(&a);
+    if (e == hipSuccess) e = hipEventCreate(&b);
+    if (e == hipSuccess) e = qs_launch_mfma_f64_rate(c, blocks, 1000, sink);
+    if (e == hipSuccess) e = hipEventRecord(a, c->stream);
+    if (e == hipSuccess) e = qs_launch_mfma_f64_rate(c, blocks, iters, sink);
+    if (e == hipSuccess) e = hipEventRecord(b, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, a, b);
+    if (a) hipEventDestroy(a);
+    if (b) hipEventDestroy(b);
+    hipFree(sink);
+    if (e != hipSuccess) return qs_fail(c, QS_E_HIP, "qs_diag_mfma_f64_rate", e);
+    const double flops = (double)blocks * 4 /* waves */ * iters * 4 /* MFMAs */ * (2.0 * 16 * 16 * 4);
+    *tflops = flops / (ms * 1e-3) / 1e12;
     return QS_OK;
 }
 

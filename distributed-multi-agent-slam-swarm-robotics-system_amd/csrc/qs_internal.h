@@ -222,6 +222,11 @@ unsigned long long *qs_frontier_total_ptr(const qs_ctx *c, void *ws);
 // icp.hip
 hipError_t qs_launch_icp_nn(qs_ctx *c, const double2 *src, size_t n_src, const double2 *dst, size_t n_dst,
                             double max_d2, int *corr, double *d2);
+hipError_t qs_launch_mfma_f64_rate(qs_ctx *c, int blocks, int iters, double *sink);
+hipError_t qs_launch_icp_prep(qs_ctx *c, const double2 *dst, size_t n_dst, size_t n_pad, double cx, double cy, double *planes);
+hipError_t qs_launch_icp_nn_mfma(qs_ctx *c, const double2 *src, size_t n_src, const double2 *dst, size_t n_dst,
+                                 const double *planes, size_t n_pad, double cx, double cy, double t2max, double max_d2,
+                                 int *corr, double *d2);
 hipError_t qs_launch_icp_sums(qs_ctx *c, const double2 *src, size_t n_src, const double2 *dst, const int *corr,
                               const double *d2, int pass, const double means[4], double *partial, double *out6);
 hipError_t qs_launch_icp_transform(qs_ctx *c, double2 *pts, size_t n, double cs, double sn, double tx, double ty);

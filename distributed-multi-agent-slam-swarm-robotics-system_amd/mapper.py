@@ -314,6 +314,22 @@ class QuasarMapper:
                                  _ptr(T), C.byref(fit), C.byref(rm), C.byref(it)), "qs_icp")
         return T.reshape(3, 3), fit.value, rm.value, it.value
 
+    def nn_search(self, src_xy, dst_xy, max_dist=1.0, mode=0):
+        """Nearest target of every source point (the correspondence step of registration_icp): (corr int32 [n], d2 float64 [n],
+        (search_ms, prep_ms)).  mode 0 auto, 1 scalar fp64, 2 MFMA-screened; results are identical."""
+        a = np.ascontiguousarray(src_xy, dtype=np.float64); b = np.ascontiguousarray(dst_xy, dtype=np.float64)
+        corr = np.empty(len(a), dtype=np.int32); d2 = np.empty(len(a), dtype=np.float64)
+        ms = np.zeros(2, dtype=np.float32)
+        self._chk(self._L.qs_nn_search(self._h, _ptr(a), len(a), _ptr(b), len(b), max_dist, mode, _ptr(corr), _ptr(d2), _ptr(ms)),
+                  "qs_nn_search")
+        return corr, d2, (float(ms[0]), float(ms[1]))
+
+    def mfma_f64_rate(self):
+        """Measured dense fp64 MFMA rate of this GPU in TFLOP/s (diagnostic)."""
+        v = C.c_double()
+        self._chk(self._L.qs_diag_mfma_f64_rate(self._h, C.byref(v)), "qs_diag_mfma_f64_rate")
+        return v.value
+
     def voxel_downsample(self, xy, voxel):
         a = np.ascontiguousarray(xy, dtype=np.float64)
         n = C.c_size_t()

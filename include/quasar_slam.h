@@ -185,6 +185,15 @@ int qs_rasterise(qs_ctx *ctx, const double *xy, size_t n, double res, int32_t di
 int qs_icp(qs_ctx *ctx, const double *src_xy, size_t n_src, const double *dst_xy, size_t n_dst,
            double max_dist, int32_t max_iter, double rel_fitness, double rel_rmse, double T[9],
            double *fitness, double *rmse, int32_t *iters);
+/* The correspondence search of registration_icp on its own (build extension; map_merger.py:48-52 reaches it through
+ * Open3D): corr[i] = nearest target of source i if closer than max_dist else -1 (ties: lowest index), d2[i] = its squared
+ * distance.  mode 0 = auto, 1 = scalar fp64 brute force, 2 = distance matrix on the matrix cores
+ * (v_mfma_f64_16x16x4_f64 as a screen with margin, fp64 re-evaluation of what passes): same results bit for bit.
+ * ms (may be NULL): HIP-event milliseconds of {the search kernel, the operand preparation}. */
+int qs_nn_search(qs_ctx *ctx, const double *src_xy, size_t n_src, const double *dst_xy, size_t n_dst,
+                 double max_dist, int32_t mode, int32_t *corr, double *d2, float ms[2]);
+/* diagnostic: measured dense fp64 MFMA rate of this GPU (TFLOP/s), the ceiling qs_nn_search mode 2 is priced against */
+int qs_diag_mfma_f64_rate(qs_ctx *ctx, double *tflops);
 /* PointCloud.voxel_down_sample(voxel): mean of the points of each voxel, ascending voxel order
  * (Open3D's order is unspecified).  out_xy == NULL queries the count. */
 int qs_voxel_downsample(qs_ctx *ctx, const double *xy, size_t n, double voxel, double *out_xy,

@@ -1008,3 +1008,39 @@ def test_fuse_kernel_many_sources_and_ranges(pkg):
         assert (gi[:off] == -1).all() and (gi[off + n:] == -1).all() and (gi[off:off + n] != -1).all()
         with pytest.raises(pkg.QuasarError):
             m.fuse_buffers_range([src[0].data_ptr()], None, 2, 4)        # ranges are multiples of 4 cells
+
+
+def test_nn_search_mfma_equals_scalar_equals_numpy(pkg):
+    """Row J1 / N3: the correspondence search on the matrix cores (v_mfma_f64_16x16x4_f64 as a screen, fp64 re-evaluation of
+    what passes) returns exactly what the scalar fp64 brute force returns -- indices and squared distances bit for bit, ties to
+    the lowest target index -- and both equal numpy's argmin over the same expression."""
+    rng = np.random.default_rng(3)
+
+    def ref(src, dst, md):
+        d2 = (src[:, None, 0] - dst[None, :, 0]) ** 2 + (src[:, None, 1] - dst[None, :, 1]) ** 2
+        j = d2.argmin(1)                                  # first minimum = lowest index
+        dm = d2[np.arange(len(src)), j]
+        ok = dm < md * md
+        return np.where(ok, j, -1).astype(np.int32), np.where(ok, dm, 0.0)
+
+    cases = []
+    for ns, nd in ((1, 1), (3, 15), (16, 16), (17, 17), (33, 63), (64, 64), (129, 1025), (1000, 777), (2048, 4099)):
+        cases.append((f"random {ns}x{nd}", rng.uniform(-50, 50, (ns, 2)), rng.uniform(-50, 50, (nd, 2)), 5.0))
+    lat = lambda n, o: rng.integers(0, 200, (n, 2)) * 0.05 + o
+    cases.append(("lattice: exact ties", lat(1500, 0.0), lat(1200, 0.0), 1.0))
+    cases.append(("lattice far from the origin", lat(900, 1.0e4), lat(1100, 1.0e4), 1.0))
+    cases.append(("half-cell offset: four equidistant targets", lat(500, 0.025), np.unique(lat(3000, 0.0), axis=0), 1.0))
+    dup = rng.uniform(-1, 1, (300, 2)); cases.append(("duplicated targets", rng.uniform(-1, 1, (400, 2)), np.concatenate([dup, dup, dup]), 0.5))
+    cases.append(("nothing in range", rng.uniform(0, 1, (100, 2)), rng.uniform(50, 51, (130, 2)), 1.0))
+    bad = rng.uniform(-5, 5, (200, 2)); bad[7] = np.nan; bad[9, 0] = np.inf
+    cases.append(("non-finite targets", rng.uniform(-5, 5, (150, 2)), bad, 2.0))
+    with pkg.QuasarMapper(64, 0.05, -1.6, -1.6) as m:
+        for name, src, dst, md in cases:
+            c1, d1, _ = m.nn_search(src, dst, md, 1)
+            c2, d2, _ = m.nn_search(src, dst, md, 2)
+            assert (c1 == c2).all() and (d1 == d2).all(), name
+            if not np.isfinite(dst).all():
+                continue
+            cr, dr = ref(src, dst, md)
+            assert (c1 == cr).all() and (d1 == dr).all(), name
+        assert m.mfma_f64_rate() > 1.0
