@@ -87,6 +87,7 @@ SIGNATURES = {
     "qs_device_buffers": (_i32, [_vp, C.POINTER(_vp), C.POINTER(_sz), C.POINTER(_vp), C.POINTER(_sz)]),
     "qs_slam_sizes": (_i32, [_vp, _i32, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     "qs_slam_closures": (_i32, [_vp, _i32, _vp, _vp, _sz]),
+    "qs_slam_closure_agents": (_i32, [_vp, _i32, _vp, _sz]),
     "qs_slam_landmarks": (_i32, [_vp, _i32, _vp, _vp, _sz]),
     "qs_slam_add_poses": (_i32, [_vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "qs_drift": (_i32, [_vp, _i32, _vp]),
@@ -106,6 +107,7 @@ SIGNATURES = {
     "qs_diag_mfma_f64_rate": (_i32, [_vp, C.POINTER(_f64)]),
     "qs_voxel_downsample": (_i32, [_vp, _vp, _sz, _f64, _vp, _sz, C.POINTER(_sz)]),
     "qs_frontier_cells": (_i32, [_vp, _vp, _sz, C.POINTER(_sz)]),
+    "qs_frontier_members": (_i32, [_vp, _vp, _sz, C.POINTER(_sz)]),
     "qs_frontier_clusters": (_i32, [_vp, _i32, _vp, _sz, C.POINTER(_sz)]),
     "qs_ekf_init": (_i32, [_vp, _i32, _f64, _vp]),
     "qs_ekf_step": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i32]),

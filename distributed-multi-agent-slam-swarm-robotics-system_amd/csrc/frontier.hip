@@ -90,7 +90,7 @@ qs_frontier_stats_kernel(int size, unsigned int *__restrict__ label, unsigned in
 template <int MODE>
 __device__ inline bool fr_pred(const unsigned int *label, const unsigned int *cnt, size_t i)
 {
-    if (MODE == 0) return label[i] != FR_NONE;
+    if (MODE == 0 || MODE == 2) return label[i] != FR_NONE;
     return cnt[i] != 0;
 }
 
@@ -159,6 +159,11 @@ qs_frontier_write_kernel(const unsigned int *__restrict__ label, const unsigned 
             const size_t slot = off + __popcll(m & ((1ull << lane) - 1));
             if (slot < cap) {
                 if (MODE == 0) { out_xy[2 * slot] = (int)(i % size); out_xy[2 * slot + 1] = (int)(i / size); }
+                else if (MODE == 2) {
+                    unsigned int r = (unsigned int)i;                       // the cluster's first cell: walk to the root
+                    for (unsigned int p = label[r]; p != r; p = label[r]) r = p;
+                    out_xy[3 * slot] = (int)(i % size); out_xy[3 * slot + 1] = (int)(i / size); out_xy[3 * slot + 2] = (int)r;
+                }
                 else {
                     out_stats[5 * slot] = cnt[i];
                     out_stats[5 * slot + 1] = (long long)(i % size); out_stats[5 * slot + 2] = (long long)(i / size);
@@ -219,6 +224,7 @@ hipError_t qs_launch_frontier_compact(qs_ctx *c, void *ws, int mode, int phase, 
         hipLaunchKernelGGL(qs_frontier_scan_kernel, dim3(1), dim3(1024), 0, c->stream, chunk, n_chunks, total);
     } else {
         if (mode == 0) hipLaunchKernelGGL(qs_frontier_write_kernel<0>, dim3((unsigned int)n_chunks), dim3(FR_BLOCK), 0, c->stream, label, cnt, sumx, sumy, cells, c->cfg.size, chunk, d_xy, d_stats, cap);
+        else if (mode == 2) hipLaunchKernelGGL(qs_frontier_write_kernel<2>, dim3((unsigned int)n_chunks), dim3(FR_BLOCK), 0, c->stream, label, cnt, sumx, sumy, cells, c->cfg.size, chunk, d_xy, d_stats, cap);
         else hipLaunchKernelGGL(qs_frontier_write_kernel<1>, dim3((unsigned int)n_chunks), dim3(FR_BLOCK), 0, c->stream, label, cnt, sumx, sumy, cells, c->cfg.size, chunk, d_xy, d_stats, cap);
     }
     return hipGetLastError();

@@ -61,7 +61,7 @@ static double r2_threshold_for(double radius)
 static void graph_free(QsGraphDev &g)
 {
     hipFree(g.lm_x); hipFree(g.lm_y); hipFree(g.lm_idx); hipFree(g.lm_type);
-    hipFree(g.cl_lm_idx); hipFree(g.cl_node_idx); hipFree(g.cl_dx); hipFree(g.cl_dy);
+    hipFree(g.cl_lm_idx); hipFree(g.cl_node_idx); hipFree(g.cl_dx); hipFree(g.cl_dy); hipFree(g.cl_agent);
     hipFree(g.dir); hipFree(g.nodes); hipFree(g.nd_next); hipFree(g.misc);
     memset(&g, 0, sizeof g);
 }
@@ -137,6 +137,7 @@ static int graph_reserve(qs_ctx *c, int g, long long need_lms, long long need_cl
         HIPCHK(c, grow_array(&G.cl_node_idx, have_cls, cap, c->stream));
         HIPCHK(c, grow_array(&G.cl_dx, have_cls, cap, c->stream));
         HIPCHK(c, grow_array(&G.cl_dy, have_cls, cap, c->stream));
+        HIPCHK(c, grow_array(&G.cl_agent, have_cls, cap, c->stream));
         G.cap_cls = cap; changed = true;
     }
     if (changed) {
@@ -551,7 +552,12 @@ extern "C" int qs_ingest(qs_ctx *c, const uint8_t *pkts, size_t n, size_t stride
     if (recv_time) HIPCHK(c, hipMemcpyAsync(c->d_time, recv_time, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
     int rc = ingest_device(c, c->d_pkts, n, stride, lens ? c->d_lens : nullptr, recv_time ? c->d_time : nullptr, seq0);
     if (rc != QS_OK) return rc;
+    // this call waits for the GPU anyway: take the graphs' real landmark / closure counts along, so that the capacity
+    // planning of the next batches starts from them and not from "every record so far was a landmark"
+    std::vector<QsGraphDev> cur((size_t)c->n_graphs);
+    HIPCHK(c, hipMemcpyAsync(cur.data(), c->d_graphs, cur.size() * sizeof(QsGraphDev), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int g = 0; g < c->n_graphs; g++) { c->lms_upper[g] = cur[g].n_lms; c->cls_upper[g] = cur[g].n_cls; }
     return QS_OK;
 }
 
@@ -727,6 +733,7 @@ static int read_graph(qs_ctx *c, int32_t graph, QsGraphDev &g)
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemcpyAsync(&g, c->d_graphs + graph, sizeof g, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->lms_upper[graph] = g.n_lms; c->cls_upper[graph] = g.n_cls;      // exact now: nothing is in flight
     return QS_OK;
 }
 
@@ -757,6 +764,19 @@ extern "C" int qs_slam_closures(qs_ctx *c, int32_t graph, int64_t *idx2, double 
     HIPCHK(c, hipMemcpy(dx.data(), g.cl_dx, n * 8, hipMemcpyDeviceToHost));
     HIPCHK(c, hipMemcpy(dy.data(), g.cl_dy, n * 8, hipMemcpyDeviceToHost));
     for (size_t i = 0; i < n; i++) { idx2[2 * i] = a[i]; idx2[2 * i + 1] = b[i]; corr2[2 * i] = dx[i]; corr2[2 * i + 1] = dy[i]; }
+    return QS_OK;
+}
+
+// agent_id of every closure's closing node (what get_correction_for_agent reads through self.nodes[node_idx], :335)
+extern "C" int qs_slam_closure_agents(qs_ctx *c, int32_t graph, uint8_t *agents, size_t cap)
+{
+    ARGCHK(c, c != nullptr && agents);
+    QsGraphDev g;
+    int rc = read_graph(c, graph, g);
+    if (rc != QS_OK) return rc;
+    const size_t n = (size_t)g.n_cls;
+    if (n > cap) return qs_fail(c, QS_E_RANGE, "qs_slam_closure_agents: capacity too small");
+    if (n) HIPCHK(c, hipMemcpy(agents, g.cl_agent, n, hipMemcpyDeviceToHost));
     return QS_OK;
 }
 
@@ -1225,8 +1245,8 @@ static int frontier_run(qs_ctx *c, int mode, int32_t min_cluster, int32_t *xy, i
     HIPCHK(c, hipSetDevice(c->device));
     if (!c->d_frontier_ws) HIPCHK(c, hipMalloc(&c->d_frontier_ws, qs_frontier_workspace_bytes(c)));
     void *ws = c->d_frontier_ws;
-    HIPCHK(c, qs_launch_frontier_label(c, ws, mode == 1));
-    HIPCHK(c, qs_launch_frontier_compact(c, ws, mode, 0, nullptr, nullptr, 0));
+    HIPCHK(c, qs_launch_frontier_label(c, ws, mode != 0));
+    HIPCHK(c, qs_launch_frontier_compact(c, ws, mode == 2 ? 0 : mode, 0, nullptr, nullptr, 0));
     unsigned long long total = 0;
     HIPCHK(c, hipMemcpyAsync(&total, qs_frontier_total_ptr(c, ws), sizeof total, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1241,6 +1261,20 @@ static int frontier_run(qs_ctx *c, int mode, int32_t min_cluster, int32_t *xy, i
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         hipFree(d);
         if (e != hipSuccess) return qs_fail(c, QS_E_HIP, "qs_frontier_cells", e);
+        return QS_OK;
+    }
+    if (mode == 2) {
+        // every frontier cell with the first cell (row-major) of its 4-connected cluster: gx, gy, root linear index
+        *n_out = (size_t)total;
+        if (!xy || total == 0) return QS_OK;
+        int *d = nullptr;
+        HIPCHK(c, hipMalloc((void **)&d, 3 * (size_t)total * sizeof(int)));
+        hipError_t e = qs_launch_frontier_compact(c, ws, 2, 1, d, nullptr, (size_t)total);
+        const size_t m = total < cap ? (size_t)total : cap;
+        if (e == hipSuccess) e = hipMemcpyAsync(xy, d, 3 * m * sizeof(int), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        hipFree(d);
+        if (e != hipSuccess) return qs_fail(c, QS_E_HIP, "qs_frontier_members", e);
         return QS_OK;
     }
     // clusters: all components come back in first-cell order; the size filter keeps that order (:228-229)
@@ -1266,6 +1300,9 @@ static int frontier_run(qs_ctx *c, int mode, int32_t min_cluster, int32_t *xy, i
 
 extern "C" int qs_frontier_cells(qs_ctx *c, int32_t *xy, size_t cap, size_t *n_out)
 { return frontier_run(c, 0, 0, xy, nullptr, cap, n_out); }
+
+extern "C" int qs_frontier_members(qs_ctx *c, int32_t *xy_root, size_t cap, size_t *n_out)
+{ return frontier_run(c, 2, 0, xy_root, nullptr, cap, n_out); }
 
 extern "C" int qs_frontier_clusters(qs_ctx *c, int32_t min_cluster, int64_t *stats5, size_t cap, size_t *n_out)
 { return frontier_run(c, 1, min_cluster, nullptr, stats5, cap, n_out); }

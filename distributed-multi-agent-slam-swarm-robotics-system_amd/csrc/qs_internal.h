@@ -51,6 +51,7 @@ struct QsGraphDev {
     unsigned char *lm_type;
     long long *cl_lm_idx, *cl_node_idx;
     double *cl_dx, *cl_dy;
+    unsigned char *cl_agent;   // agent_id of the closing node (nodes[node_idx].agent_id, :335)
     QsDirEntry *dir;       // [QS_NTYPES][hmask + 1]
     QsLmNode *nodes;       // [node_cap]: node 0 is the null node, node 1 + t the FIRST node of directory entry t (a query
                            // goes straight to it: no directory round trip), the pool of overflow nodes after those

@@ -435,6 +435,7 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
         const long long n_cls0 = n_cls, cap_cls = Gp->cap_cls;
         long long *const cl_lm_idx = Gp->cl_lm_idx, *const cl_node_idx = Gp->cl_node_idx;
         double *const cl_dx = Gp->cl_dx, *const cl_dy = Gp->cl_dy;
+        unsigned char *const cl_agent = Gp->cl_agent;
         unsigned long long st_windows = 0, st_a = 0, st_b = 0;
         const unsigned long long t0_cyc = __builtin_amdgcn_s_memtime(), t0_real = __builtin_amdgcn_s_memrealtime();
         // the window it prepared (its closure records are written one phase later)
@@ -461,6 +462,7 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
                     if (slot < cap_cls) {
                         cl_lm_idx[slot] = m_idx; cl_node_idx[slot] = idx;                      // :317
                         cl_dx[slot] = cdx; cl_dy[slot] = cdy;
+                        cl_agent[slot] = (unsigned char)(bot0 + a);
                     }
                     const unsigned int pos = s_acnt[a];
                     sb.acl_node[pos] = idx; sb.acl_dx[pos] = s_dx[par][a]; sb.acl_dy[pos] = s_dy[par][a];   // :911-914

@@ -52,6 +52,7 @@ class QuasarMapper:
         self.bots_per_graph = bots_per_graph if bots_per_graph > 0 else max_agent
         self.n_graphs = (max_agent + self.bots_per_graph - 1) // self.bots_per_graph
         self._last_n = 0
+        self._map_version = 0          # bumped by everything that can change a cell: the look-alike's .grid cache key
         self.occ_grid = OccupancyGrid._attached(self)
         self.slam = PoseGraphSLAM._attached(self)
 
@@ -78,6 +79,7 @@ class QuasarMapper:
 
     def reset(self):
         self._chk(self._L.qs_reset(self._h), "qs_reset")
+        self._map_version += 1
 
     def sync(self):
         self._chk(self._L.qs_sync(self._h), "qs_sync")
@@ -113,6 +115,7 @@ class QuasarMapper:
             raise ValueError("recv_time must have one entry per record")
         self._chk(self._L.qs_ingest(self._h, _ptr(buf), n, stride, _ptr(lens), _ptr(t),
                                     UINT64_MAX if seq0 is None else int(seq0)), "qs_ingest")
+        self._map_version += 1
         self._last_n = n
         return n
 
@@ -122,6 +125,7 @@ class QuasarMapper:
                                            C.c_void_p(d_lens) if d_lens else None,
                                            C.c_void_p(d_time) if d_time else None,
                                            UINT64_MAX if seq0 is None else int(seq0)), "qs_ingest_device")
+        self._map_version += 1
         self._last_n = n
 
     def last_batch(self):
@@ -165,6 +169,7 @@ class QuasarMapper:
         v = np.ascontiguousarray(valid, dtype=np.uint8)
         self._chk(self._L.qs_update_rays(self._h, *[_ptr(x) for x in a], _ptr(v), len(v),
                                          UINT64_MAX if seq0 is None else int(seq0)), "qs_update_rays")
+        self._map_version += 1
 
     def world_to_grid(self, w, axis=0):
         w = np.ascontiguousarray(w, dtype=np.float64)
@@ -173,7 +178,9 @@ class QuasarMapper:
         return out
 
     def device_buffers(self):
-        """(stamps_ptr, stamps_bytes, counts_ptr, counts_bytes) raw device addresses."""
+        """(stamps_ptr, stamps_bytes, counts_ptr, counts_bytes) raw device addresses.  Whoever gets them may write the
+        grid (a collective): the look-alike's cached .grid is dropped."""
+        self._map_version += 1
         sp, cp = C.c_void_p(), C.c_void_p()
         sb, cb = C.c_size_t(), C.c_size_t()
         self._chk(self._L.qs_device_buffers(self._h, C.byref(sp), C.byref(sb), C.byref(cp), C.byref(cb)),
@@ -185,6 +192,14 @@ class QuasarMapper:
         a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
         self._chk(self._L.qs_slam_sizes(self._h, graph, C.byref(a), C.byref(b), C.byref(c)), "qs_slam_sizes")
         return a.value, b.value, c.value
+
+    def closure_agents(self, graph=0):
+        """agent_id of each closure's closing node (self.nodes[node_idx].agent_id in the reference, :335)."""
+        n = self.slam_sizes(graph)[2]
+        out = np.zeros(n, dtype=np.uint8)
+        if n:
+            self._chk(self._L.qs_slam_closure_agents(self._h, graph, _ptr(out), n), "qs_slam_closure_agents")
+        return out
 
     def closures(self, graph=0):
         n = self.slam_sizes(graph)[2]
@@ -242,12 +257,14 @@ class QuasarMapper:
     def fuse(self, others):
         arr = (C.c_void_p * len(others))(*[o._h for o in others])
         self._chk(self._L.qs_fuse(self._h, arr, len(others)), "qs_fuse")
+        self._map_version += 1
 
     def fuse_buffers(self, stamp_ptrs, count_ptrs=None):
         n = len(stamp_ptrs)
         sp = (C.c_void_p * n)(*stamp_ptrs)
         cp = (C.c_void_p * n)(*count_ptrs) if count_ptrs else None
         self._chk(self._L.qs_fuse_buffers(self._h, sp, cp, n), "qs_fuse_buffers")
+        self._map_version += 1
 
     def fuse_buffers_range(self, stamp_ptrs, count_ptrs, cell_offset, n_cells, counts_into_fused=False):
         """Fold peers' copies of cells [cell_offset, cell_offset + n_cells) into this grid (raw device addresses of the
@@ -257,6 +274,7 @@ class QuasarMapper:
         cp = (C.c_void_p * n)(*count_ptrs) if count_ptrs else None
         self._chk(self._L.qs_fuse_buffers_range(self._h, sp, cp, n, cell_offset, n_cells, int(counts_into_fused)),
                   "qs_fuse_buffers_range")
+        self._map_version += 1
 
     def fused_counts(self):
         """Snapshot the local counters into the context's second buffer -> (device address, bytes); a collective sums
@@ -361,6 +379,16 @@ class QuasarMapper:
                       "qs_frontier_clusters")
         return st
 
+    def frontier_members(self):
+        """int32 [n, 3]: every frontier cell (gx, gy) in row-major order with the linear index of the first cell of its
+        4-connected cluster (clusters labelled on the device)."""
+        n = C.c_size_t()
+        self._chk(self._L.qs_frontier_members(self._h, None, 0, C.byref(n)), "qs_frontier_members")
+        out = np.zeros((n.value, 3), dtype=np.int32)
+        if n.value:
+            self._chk(self._L.qs_frontier_members(self._h, _ptr(out), n.value, C.byref(n)), "qs_frontier_members")
+        return out
+
     def frontier_centroids(self, min_cluster=3):
         """[cluster_centroid_world(c) for c in clusters] (:955): mean cell index by true division,
         then grid_to_world (:127-131, cell centre)."""
@@ -427,7 +455,13 @@ class OccupancyGrid:
 
     @property
     def grid(self):
-        return self._m.grid_i8()
+        """np.int8 [size, size], indexed [gy, gx] (:119).  Downloaded from the GPU once per change of the map, not per
+        access: the renderer reads occ_grid.grid[gy, gx] cell by cell (:505-516)."""
+        v = self._m._map_version
+        if getattr(self, "_grid_cache", None) is None or self._grid_cache[0] != v:
+            self._grid_cache = (v, self._m.grid_i8())
+            self.downloads = getattr(self, "downloads", 0) + 1
+        return self._grid_cache[1]
 
     def world_to_grid(self, wx, wy):                      # :121-125
         gx = int((wx - self.ox) / self.res)
@@ -449,8 +483,60 @@ class OccupancyGrid:
     def get_frontiers(self):                              # :181-196
         return [tuple(c) for c in self._m.frontier_cells().tolist()]
 
+    def cluster_frontiers(self, frontier_cells=None, min_cluster=P.FRONTIER_MIN_CLUSTER):     # :198-231
+        """Clusters of 4-connected frontier cells with at least FRONTIER_MIN_CLUSTER members, in the reference's cluster
+        order (by first cell, row-major), each a list of (gx, gy).  The labelling runs on the device over the current
+        grid; `frontier_cells`, if given, must be get_frontiers() of that grid (as main() passes it, :951-952).  Inside a
+        cluster the cells come in row-major order, not in the reference's BFS visiting order (nothing reads that order:
+        the reference only takes len() and the coordinate sums, :233-237)."""
+        mem = self._m.frontier_members()
+        if frontier_cells is not None and len(frontier_cells) != len(mem):
+            raise ValueError("cluster_frontiers: frontier_cells is not get_frontiers() of the current grid")
+        if len(mem) == 0:
+            return []
+        order = np.argsort(mem[:, 2], kind="stable")                 # by cluster (= by first cell), row-major inside
+        roots, start = np.unique(mem[order, 2], return_index=True)
+        bounds = list(start) + [len(mem)]
+        out = []
+        for k in range(len(roots)):
+            cells = mem[order[bounds[k]:bounds[k + 1]], :2]
+            if len(cells) >= min_cluster:
+                out.append([(int(x), int(y)) for x, y in cells])
+        return out
+
+    def cluster_centroid_world(self, cluster):                       # :233-237
+        avg_x = sum(c[0] for c in cluster) / len(cluster)
+        avg_y = sum(c[1] for c in cluster) / len(cluster)
+        return self.grid_to_world(avg_x, avg_y)
+
     def frontier_centroids(self, min_cluster=P.FRONTIER_MIN_CLUSTER):    # :951-956
         return self._m.frontier_centroids(min_cluster)
+
+
+class _Node:
+    __slots__ = ("index", "agent_id")
+
+    def __init__(self, index, agent_id):
+        self.index, self.agent_id = index, agent_id
+
+
+class _NodeList:
+    def __init__(self, mapper, graph):
+        self._n = mapper.slam_sizes(graph)[0]
+        idx, _ = mapper.closures(graph)
+        self._agent = dict(zip((int(v) for v in idx[:, 1]), (int(a) for a in mapper.closure_agents(graph))))
+
+    def __len__(self):
+        return self._n
+
+    def __getitem__(self, i):
+        if i < 0:
+            i += self._n
+        if not 0 <= i < self._n:
+            raise IndexError(i)
+        if i not in self._agent:
+            raise KeyError(f"node {i}: only the closing nodes of closures keep their agent_id on the host side")
+        return _Node(i, self._agent[i])
 
 
 class PoseGraphSLAM:
@@ -475,6 +561,12 @@ class PoseGraphSLAM:
     @property
     def n_nodes(self):
         return self._m.slam_sizes(self._g)[0]
+
+    @property
+    def nodes(self):
+        """self.nodes (:268) as far as the reference reads it: len(nodes) (:275) and nodes[node_idx].agent_id for the
+        closing node of a closure (:335).  The poses themselves stay on the device (qs_last_batch returns a batch's)."""
+        return _NodeList(self._m, self._g)
 
     def add_pose(self, x, y, yaw, agent_id, landmark_type, timestamp=0.0):
         """dual_bot_mapper.py:273-290: returns (closure_detected, correction_dx, correction_dy).  The

@@ -36,16 +36,19 @@ class SessionLog:
         # point_clouds[bot][sensor] in arrival order (:764-767), kept for the exit-time files
         self._clouds = {b: {s: [] for s in P.SENSOR_NAMES} for b in range(1, max_agent + 1)}
 
-    def log_batch(self, buf, accepted, pose, hits_xy, hits_valid, recv_time):
+    def log_batch(self, buf, accepted, pose, hits_xy, hits_valid, recv_time, lengths=None):
         """One ingested batch: buf uint8 [n, stride] datagrams, accepted / pose from
-        QuasarMapper.last_batch(), hits from last_hits(), recv_time float [n]."""
+        QuasarMapper.last_batch(), hits from last_hits(), recv_time float [n]; lengths: per-datagram lengths (None: every
+        datagram fills its slot).  A 41-byte v1 datagram has no landmark byte: LM_NONE (:832-836), whatever an earlier,
+        longer datagram left in the slot's tail."""
         n = len(accepted)
         for i in range(n):
             if not accepted[i]:
                 continue
             rec = np.frombuffer(buf[i, :42].tobytes() if buf.shape[1] >= 42 else buf[i].tobytes() + b"\0", dtype=P.PACKET_DTYPE)[0]
             agent = int(rec["agent"])
-            lm = int(rec["lm"]) if buf.shape[1] >= 42 else 0
+            ln = buf.shape[1] if lengths is None else int(lengths[i])
+            lm = int(rec["lm"]) if ln >= 42 else 0
             now = float(recv_time[i])
             rx, ry, ryaw = pose[i]
             self._w_telem.writerow([                                  # :867-874

@@ -125,6 +125,8 @@ int qs_slam_sizes(qs_ctx *ctx, int32_t graph, int64_t *n_nodes, int64_t *n_landm
                   int64_t *n_closures);
 /* slam.closures: (lm_idx, node_idx), (corr_dx, corr_dy)  :270, :317 */
 int qs_slam_closures(qs_ctx *ctx, int32_t graph, int64_t *idx2, double *corr2, size_t cap);
+/* nodes[node_idx].agent_id of every closure's closing node (get_correction_for_agent, :328-338) */
+int qs_slam_closure_agents(qs_ctx *ctx, int32_t graph, uint8_t *agents, size_t cap);
 /* slam.landmarks: (x, y), (type, node_idx) in insertion order  :269, :288 */
 int qs_slam_landmarks(qs_ctx *ctx, int32_t graph, double *xy, int64_t *type_idx, size_t cap);
 /* PoseGraphSLAM.add_pose(x, y, yaw, agent_id, landmark_type, timestamp) -> (closure_detected,
@@ -208,6 +210,10 @@ int qs_frontier_cells(qs_ctx *ctx, int32_t *xy, size_t cap, size_t *n_out);
  * first cell, row-major); 5 values per cluster: size, first_gx, first_gy, sum_gx, sum_gy.
  * stats5 == NULL queries the count. */
 int qs_frontier_clusters(qs_ctx *ctx, int32_t min_cluster, int64_t *stats5, size_t cap, size_t *n_out);
+
+/* cluster membership: every frontier cell (row-major order) with the linear index (gy*size + gx) of the first cell of
+ * its 4-connected cluster; 3 values per cell: gx, gy, root.  xy_root == NULL queries the count. */
+int qs_frontier_members(qs_ctx *ctx, int32_t *xy_root, size_t cap, size_t *n_out);
 
 /* ---- EKF  AgentFirmware_Bot1/ekf.cpp:5-92 ---------------------------------------------- */
 /* On ingest (qs_config.enable_ekf) the filter of every bot runs over the batch: batches of >= 4096

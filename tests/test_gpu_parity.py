@@ -1044,3 +1044,62 @@ def test_nn_search_mfma_equals_scalar_equals_numpy(pkg):
             cr, dr = ref(src, dst, md)
             assert (c1 == cr).all() and (d1 == dr).all(), name
         assert m.mfma_f64_rate() > 1.0
+
+
+@pytest.mark.parametrize("name", ["session_200", "laps5_512", "adversarial_dense_200"])
+def test_object_api_the_reference_callers_use(pkg, name):
+    """the look-alikes of what main() and MapRenderer touch.
+      * occ_grid.cluster_frontiers(cells) / cluster_centroid_world(cluster) (:951-955) against the reference's own clusters;
+      * slam.nodes: len() and nodes[node_idx].agent_id, so that get_correction_for_agent's loop (:328-338) works as written;
+      * occ_grid.grid read cell by cell as the renderer does (:505-516) costs ONE download per change of the map."""
+    fr = load("frontiers")
+    g = load(name)
+    with make_mapper(pkg, g) as m:
+        og, slam = m.occ_grid, m.slam
+        m.ingest_array(g["datagrams"], g["lengths"])
+        # -- main() :951-955, verbatim call pattern
+        frontier_cells = og.get_frontiers()
+        clusters = og.cluster_frontiers(frontier_cells)
+        centroids = [og.cluster_centroid_world(c) for c in clusters]
+        assert [len(c) for c in clusters] == fr[name + "_sizes"].tolist()
+        assert [min(c, key=lambda p: (p[1], p[0])) for c in clusters] == [tuple(v) for v in fr[name + "_first"].tolist()]
+        assert [[sum(p[0] for p in c), sum(p[1] for p in c)] for c in clusters] == fr[name + "_sums"].tolist()
+        assert (np.array(centroids).reshape(-1, 2) == fr[name + "_centroids"]).all()
+        cellset = set(frontier_cells)
+        for c in clusters:                                  # every cluster is 4-connected inside the frontier set
+            assert set(c) <= cellset
+            seen, todo = {c[0]}, [c[0]]
+            while todo:
+                x, y = todo.pop()
+                for nb in ((x - 1, y), (x + 1, y), (x, y - 1), (x, y + 1)):
+                    if nb in cellset and nb not in seen:
+                        seen.add(nb); todo.append(nb)
+            assert seen == set(c)
+        with pytest.raises(ValueError):
+            og.cluster_frontiers(frontier_cells[:-1])
+        # -- PoseGraphSLAM.get_correction_for_agent, the reference's loop (:328-338) on the look-alike's attributes
+        assert len(slam.nodes) == int(g["n_nodes"][0])
+        nodes = slam.nodes
+        for agent_id in (1, 2):
+            tx = ty = 0.0
+            for lm_idx, node_idx, cdx, cdy in slam.closures:
+                if nodes[node_idx].agent_id == agent_id:
+                    tx += cdx; ty += cdy
+            assert abs(tx - m.drift(agent_id)[0]) < 1e-9 and abs(ty - m.drift(agent_id)[1]) < 1e-9
+            assert np.abs(np.array(slam.get_correction_for_agent(agent_id)) - g["drift"][agent_id - 1]).max() < FLOAT_TOL
+        # -- MapRenderer's read pattern (:505-516)
+        og.downloads = 0
+        size = og.size
+        free = 0
+        for gy in range(0, size, 7):
+            for gx in range(0, size, 7):
+                val = og.grid[gy, gx]
+                if val == 0:
+                    free += 1
+        assert og.downloads == 1 and free > 0
+        assert hashlib.sha256(og.grid.tobytes()).digest() == g["grid_sha256"].tobytes()
+        og.update_ray(0.0, 0.0, 1.0, 0.5, True)             # any write drops the cached copy ...
+        assert og.grid[og.world_to_grid(1.0, 0.5)[1], og.world_to_grid(1.0, 0.5)[0]] == 100 and og.downloads == 2
+        for _ in range(50):                                  # ... and the object API's per-ray calls reuse their staging
+            og.update_ray(0.0, 0.0, -1.0, 0.25, False)
+        assert og.downloads == 2 and og.grid is og.grid

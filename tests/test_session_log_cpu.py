@@ -49,3 +49,24 @@ def test_session_files_roundtrip(tmp_path):
     cl = list(csv.reader(open(tmp_path / "slam_closures.csv")))
     assert cl[0] == ["node_i", "node_j", "corr_dx", "corr_dy"] and len(cl) == 11
     assert cl[1] == ["236", "267", "-0.2363", "0.0045"]
+
+
+def test_v1_datagram_in_a_reused_slot_logs_no_landmark(tmp_path):
+    """MissionControl reuses its 48-byte slots; a 41-byte v1 datagram written over an earlier 42-byte one
+    leaves that one's landmark byte in the slot's tail.  The reference forces LM_NONE for v1 packets (:832-836)."""
+    import csv
+    import importlib
+    from conftest import PKG_NAME
+    P = importlib.import_module(PKG_NAME + ".protocol")
+    SL = importlib.import_module(PKG_NAME + ".session_log")
+    buf = np.zeros((2, 48), dtype=np.uint8)
+    v2 = P.pack_packets([1], [0.5], [0.25], [0.0], [7], [9], np.array([[0.3, 0.4, 0.5, 0.6]]), [5])[0]
+    buf[0, :42] = v2
+    buf[1, :42] = v2                      # the slot's previous tenant: landmark 5 at byte 41 ...
+    lengths = np.array([42, 41], dtype=np.uint16)     # ... under a v1 datagram of 41 bytes
+    log = SL.SessionLog(str(tmp_path), max_agent=2)
+    acc = np.ones(2, dtype=np.uint8); pose = np.zeros((2, 3)); hxy = np.zeros((2, 4, 2)); hv = np.zeros((2, 4), dtype=np.uint8)
+    log.log_batch(buf, acc, pose, hxy, hv, np.array([0.0, 0.1]), lengths=lengths)
+    log.close()
+    rows = list(csv.DictReader(open(tmp_path / "telemetry.csv")))
+    assert [int(r["landmark"]) for r in rows] == [5, 0]
