@@ -14,7 +14,7 @@ HEADER = os.path.join(os.path.dirname(_HERE), "include", "quasar_slam.h")
 
 QS_CNT_NAMES = ("datagrams", "accepted", "rays", "cells", "hits", "closures", "landmarks", "rebases",
                 "slam_windows", "slam_rounds", "slam_node_iters", "slam_misc_iters", "slam_cycles",
-                "slam_realtime_100mhz", "slam_cyc_prepare", "slam_cyc_query", "slam_cyc_commit", "ekf_wrap_clamp")
+                "slam_realtime_100mhz", "slam_cyc_prepare", "slam_cyc_query", "slam_cyc_commit", "ekf_wrap_clamp", "edge_rays")
 QS_STAGE_NAMES = ("decode", "slam", "raycast", "ekf", "slam_chain", "rc_rays", "rc_sort", "rc_raster")
 UINT64_MAX = (1 << 64) - 1
 
@@ -39,7 +39,8 @@ class QsConfig(C.Structure):
         ("seq_stride", C.c_int32),
         ("shard_bots", C.c_int32),
         ("shard_rank", C.c_int32),
-        ("reserved", C.c_int32 * 4),
+        ("exact_trig", C.c_int32),
+        ("reserved", C.c_int32 * 3),
     ]
 
 

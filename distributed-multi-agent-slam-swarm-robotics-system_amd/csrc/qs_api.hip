@@ -45,6 +45,7 @@ extern "C" int qs_config_default(qs_config *cfg)
     cfg->ekf_metres_per_tick = 0.0107;        // simulation_tools/generate_fake_dual_session.py:462
     cfg->device = 0;
     cfg->raycast_mode = 0;
+    cfg->exact_trig = 1;
     return QS_OK;
 }
 
@@ -172,7 +173,7 @@ static int reset_state(qs_ctx *c)
     // closure (:271).  All enqueued: a reset does not wait for the GPU.
     HIPCHK(c, qs_launch_slam_reset_index(c));
     for (int g = 0; g < c->n_graphs; g++) { c->lms_upper[g] = 0; c->cls_upper[g] = 0; }
-    c->next_seq = 0; c->epoch_base = 0; c->last_n = 0; c->last_has_poses = false; c->n_rebases = 0;
+    c->next_seq = 0; c->epoch_base = 0; c->last_n = 0; c->last_has_poses = false; c->n_rebases = 0; c->edge_rays_total = 0;
     return QS_OK;
 }
 
@@ -254,6 +255,7 @@ static void free_batch(qs_ctx *c)
     hipFree(b.accept); hipFree(b.agent); hipFree(b.lm); hipFree(b.px); hipFree(b.py); hipFree(b.yaw);
     hipFree(b.dist); hipFree(b.enc); hipFree(b.rx); hipFree(b.ry); hipFree(b.hit); hipFree(b.hit_valid);
     if (b.map_ok != b.accept) hipFree(b.map_ok);
+    hipFree(b.edge); hipFree(b.edge_n);
     memset(&b, 0, sizeof b);
     QsSlamBatch &sb = c->sb;
     hipFree(sb.node); hipFree(sb.ev_node); hipFree(sb.ev_agent); hipFree(sb.ev_type); hipFree(sb.ev_px); hipFree(sb.ev_py);
@@ -369,6 +371,7 @@ static int ensure_batch(qs_ctx *c, size_t n)
         b.own_lo = c->cfg.shard_rank * c->cfg.shard_bots + 1;
         b.own_hi = std::min(c->cfg.max_agent, (c->cfg.shard_rank + 1) * c->cfg.shard_bots);
     } else { b.map_ok = b.accept; b.own_lo = 1; b.own_hi = c->cfg.max_agent; }
+    if (c->cfg.exact_trig) { HIPCHK(c, dev_realloc(&b.edge, 4 * cap)); if (!b.edge_n) HIPCHK(c, hipMalloc((void **)&b.edge_n, sizeof(unsigned int))); }
     QsSlamBatch &sb = c->sb;
     const size_t nblk = (size_t)qs_slam_blocks(cap), G = (size_t)c->n_graphs, nb = (size_t)c->cfg.max_agent + 2;
     HIPCHK(c, dev_realloc(&sb.node, cap)); HIPCHK(c, dev_realloc(&sb.ev_node, cap));
@@ -474,6 +477,44 @@ static int reserve_graphs_for_batch(qs_ctx *c, size_t n)
     return QS_OK;
 }
 
+static int io_reserve(qs_ctx *c, size_t bytes);
+// Exact-trig mode (qs_config.exact_trig, default on): rays the device did not decide (raycast_common.h, qs_edge_ray) get
+// their end points from libm -- math.cos / math.sin of the reference are glibc's -- and are cast with the stamps the
+// ingest would have given them.  Costs one 4-byte read-back per ingest (the call then ends with a stream sync).
+static int resolve_edge_rays(qs_ctx *c, uint64_t seq0)
+{
+    unsigned int n_edge = 0;
+    HIPCHK(c, hipMemcpyAsync(&n_edge, c->b.edge_n, sizeof n_edge, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->edge_rays_total += n_edge;
+    if (n_edge == 0) return QS_OK;
+    const size_t bytes = (size_t)n_edge * 5 * sizeof(double);
+    int rc = io_reserve(c, bytes);
+    if (rc != QS_OK) return rc;
+    double *d = (double *)c->d_io_ws;
+    std::vector<double> h((size_t)n_edge * 5);
+    HIPCHK(c, qs_launch_edge_gather(c, n_edge, d));
+    HIPCHK(c, hipMemcpyAsync(h.data(), d, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::vector<unsigned int> ids(n_edge);
+    HIPCHK(c, hipMemcpy(ids.data(), c->b.edge, n_edge * sizeof(unsigned int), hipMemcpyDeviceToHost));
+    static const double kPi = 3.141592653589793;                                              // math.pi
+    static const double off[4] = {0.0, kPi / 2, kPi, -kPi / 2};                               // :61-66
+    for (unsigned int e = 0; e < n_edge; e++) {
+        const double rx = h[5 * e], ry = h[5 * e + 1], yaw = h[5 * e + 2], dd = h[5 * e + 3];
+        const double a = yaw + off[ids[e] & 3];                                                // :887
+        const bool valid = (c->cfg.min_dist < dd) && (dd <= c->cfg.max_dist);                  // :888
+        const double range = valid ? dd : ((dd > c->cfg.min_dist) ? ((c->cfg.max_dist < dd) ? c->cfg.max_dist : dd) : c->cfg.max_dist);   // :900
+        h[5 * e + 2] = rx + range * cos(a);                                                    // :890 / :901
+        h[5 * e + 3] = ry + range * sin(a);                                                    // :891 / :902
+        h[5 * e + 4] = valid ? 1.0 : 0.0;
+    }
+    HIPCHK(c, hipMemcpyAsync(d, h.data(), bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, qs_launch_edge_cast(c, n_edge, d, seq0));
+    HIPCHK(c, hipStreamSynchronize(c->stream));                                                // h goes out of scope
+    return QS_OK;
+}
+
 static int ingest_device(qs_ctx *c, const uint8_t *d_pkts, size_t n, size_t stride, const uint16_t *d_lens,
                          const double *d_time, uint64_t seq0)
 {
@@ -489,6 +530,7 @@ static int ingest_device(qs_ctx *c, const uint8_t *d_pkts, size_t n, size_t stri
     if (rc != QS_OK) return rc;
     HIPCHK(c, hipMemsetAsync(c->d_graph_batch, 0, (size_t)c->n_graphs * 2 * sizeof(unsigned long long), c->stream));
     HIPCHK(c, hipMemsetAsync(c->sb.agent_ev, 0, ((size_t)c->cfg.max_agent + 2) * sizeof(unsigned int), c->stream));
+    if (c->b.edge_n) HIPCHK(c, hipMemsetAsync(c->b.edge_n, 0, sizeof(unsigned int), c->stream));
     { StageTimer t(c, QS_STAGE_DECODE); HIPCHK(c, qs_launch_decode(c, d_pkts, n, stride, d_lens)); t.stop(); }
     rc = reserve_graphs_for_batch(c, n);
     if (rc != QS_OK) return rc;
@@ -516,6 +558,7 @@ static int ingest_device(qs_ctx *c, const uint8_t *d_pkts, size_t n, size_t stri
         t.stop();
     }
     if (c->cfg.enable_ekf) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_ekf_done, 0));   // join
+    if (c->b.edge) { rc = resolve_edge_rays(c, seq0); if (rc != QS_OK) return rc; }
     c->next_seq = seq0 + n * sstride;
     c->dirty_since_fuse = true;
     return QS_OK;
@@ -1365,5 +1408,6 @@ extern "C" int qs_counters(qs_ctx *c, uint64_t out[QS_CNT_N])
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (int i = 0; i < QS_CNT_N; i++) out[i] = v[i];
     out[QS_CNT_REBASES] = c->n_rebases;
+    out[QS_CNT_EDGE_RAYS] = c->edge_rays_total;
     return QS_OK;
 }

@@ -94,6 +94,8 @@ struct QsBatch {
     unsigned char *map_ok;   // 1 = accepted AND this context casts its rays / runs its filter: the same array as accept
                              // unless the context is one shard of a replicated-pose-graph deployment (qs_config.shard_bots)
     int own_lo, own_hi;      // agents whose rays this context casts (1..max_agent when not sharded)
+    unsigned int *edge;      // exact-trig mode: rays (4 * record + sensor) whose end point lies within 1e-9 cells of a cell
+    unsigned int *edge_n;    //   boundary are not cast by the device but listed here; the host resolves them (qs_api.hip)
     unsigned char *agent;    // agent_id
     unsigned char *lm;       // landmark_type (0 for v1 packets)
     double *px, *py, *yaw;   // f32 fields widened; px already has the bot offset (:851-852)
@@ -154,6 +156,7 @@ struct qs_ctx {
     void *d_ekf_ws = nullptr; size_t ekf_ws_bytes = 0;   // parallel-in-time EKF workspace (ekf_scan.hip)
 
     uint64_t next_seq = 0, epoch_base = 0, n_rebases = 0;
+    uint64_t edge_rays_total = 0;                // exact-trig mode: rays resolved on the host since the last reset
 
     // timing
     bool timing = false;
@@ -191,6 +194,8 @@ int qs_slam_blocks(size_t n);
 // raycast.hip
 #define QS_DIRECT_MAX_BATCH 256   // raycast_mode auto: batches up to this size take the direct kernel
 hipError_t qs_launch_raycast_direct(qs_ctx *c, size_t n, uint64_t seq0);
+hipError_t qs_launch_edge_gather(qs_ctx *c, unsigned int n_edge, double *d_out);
+hipError_t qs_launch_edge_cast(qs_ctx *c, unsigned int n_edge, const double *d_in, uint64_t seq0);
 hipError_t qs_launch_hits(qs_ctx *c, size_t n);                 // ray end points of the resident batch (qs_last_hits)
 hipError_t qs_launch_update_rays(qs_ctx *c, const double *rx, const double *ry, const double *hx,
                                  const double *hy, const unsigned char *valid, size_t n,

@@ -60,6 +60,21 @@ __device__ inline QsRay qs_project_ray(double rx, double ry, double yaw, double 
     return r;
 }
 
+// Exact-trig mode.  The device library's sin / cos may differ from glibc's (the reference's math.cos / math.sin) in
+// the last bit; after `r * cos + rx` that is at most one ulp of the end point (< 6e-13 cells at 200 m and 5 cm), which
+// can only change int((w - o) / res) if the quotient lies that close to an integer.  Rays whose end-point quotient is
+// within 1e-9 (+ 1e-14 relative) of an integer on either axis are therefore not decided here: the host recomputes their
+// end points with libm and casts them with their own stamps (any order gives the same grid).
+__device__ inline bool qs_edge_coord(double w, double o, const QsGeom &geo)
+{
+    const double qa = (w - o) * geo.inv_res;
+    return fabs(qa - rint(qa)) <= 1.0e-9 + fabs(qa) * 1.0e-14;
+}
+__device__ inline bool qs_edge_ray(const QsRay &ray, const QsGeom &geo)
+{
+    return qs_edge_coord(ray.ex, geo.ox, geo) || qs_edge_coord(ray.ey, geo.oy, geo);
+}
+
 struct QsLine { int x0, y0, x1, y1, dx, dy, sx, sy; };
 
 // Grid end points of a ray and the Bresenham set-up of :158-165.  Returns false when no cell

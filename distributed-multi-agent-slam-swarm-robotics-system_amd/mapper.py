@@ -27,7 +27,7 @@ class QuasarMapper:
                  enable_counts=True, enable_ekf=False, device=0, raycast_mode=0,
                  ekf_metres_per_tick=0.0107, min_poses_between=P.MIN_POSES_BETWEEN,
                  closure_radius=P.CLOSURE_RADIUS, closure_correction=P.CLOSURE_CORRECTION,
-                 seq_stride=1, shard_bots=0, shard_rank=0):
+                 seq_stride=1, shard_bots=0, shard_rank=0, exact_trig=True):
         self._L = _lib.load()
         cfg = QsConfig()
         check(None, self._L.qs_config_default(C.byref(cfg)), "qs_config_default")
@@ -41,6 +41,7 @@ class QuasarMapper:
         cfg.closure_radius, cfg.closure_correction = closure_radius, closure_correction
         cfg.seq_stride = seq_stride
         cfg.shard_bots, cfg.shard_rank = shard_bots, shard_rank
+        cfg.exact_trig = int(bool(exact_trig))
         self.cfg = cfg
         self.size, self.res, self.ox, self.oy = size, resolution, origin_x, origin_y
         self.max_agent = max_agent

@@ -65,7 +65,11 @@ typedef struct qs_config {
                                    rays, keeps zones and runs the EKF only for its own agents
                                    shard_rank*shard_bots+1 .. (shard_rank+1)*shard_bots.  0 = the context owns every agent */
     int32_t shard_rank;
-    int32_t reserved[4];
+    int32_t exact_trig;         /* 1 (default): rays whose end point falls within 1e-9 cells of a cell boundary -- where a last-bit
+                                   difference between the device's sin / cos and glibc's (CPython's math.cos / math.sin) could
+                                   change a cell index -- are resolved on the host with libm; every ingest then ends with one
+                                   stream synchronisation.  0: device trig only, qs_ingest_device stays asynchronous */
+    int32_t reserved[3];
 } qs_config;
 
 /* reference constants (dual_bot_mapper.py:57-99) */
@@ -231,7 +235,7 @@ int qs_ekf_state(qs_ctx *ctx, int32_t bot, double x[6], double P[36]);
 enum { QS_CNT_DATAGRAMS = 0, QS_CNT_ACCEPTED, QS_CNT_RAYS, QS_CNT_CELLS, QS_CNT_HITS,
        QS_CNT_CLOSURES, QS_CNT_LANDMARKS, QS_CNT_REBASES, QS_CNT_SLAM_WINDOWS, QS_CNT_SLAM_ROUNDS,
        QS_CNT_SLAM_NODE_ITERS, QS_CNT_SLAM_MISC_ITERS, QS_CNT_SLAM_CYCLES, QS_CNT_SLAM_REALTIME, QS_CNT_SLAM_CYC_A, QS_CNT_SLAM_CYC_B,
-       QS_CNT_SLAM_CYC_C, QS_CNT_EKF_WRAP_CLAMP, QS_CNT_N };
+       QS_CNT_SLAM_CYC_C, QS_CNT_EKF_WRAP_CLAMP, QS_CNT_EDGE_RAYS /* exact_trig: rays resolved on the host */, QS_CNT_N };
 int qs_counters(qs_ctx *ctx, uint64_t out[QS_CNT_N]);
 /* HIP-event timing of the pipeline stages on the context's stream.  enable != 0 brackets
  * each stage of every ingest with events; qs_stage_times returns accumulated ms and the

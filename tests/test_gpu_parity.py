@@ -1103,3 +1103,88 @@ def test_object_api_the_reference_callers_use(pkg, name):
         for _ in range(50):                                  # ... and the object API's per-ray calls reuse their staging
             og.update_ray(0.0, 0.0, -1.0, 0.25, False)
         assert og.downloads == 2 and og.grid is og.grid
+
+
+def _one_packet(P, x, y, yaw, d4, agent=1, lm=0):
+    return P.pack_packets([agent], [x], [y], [yaw], [0], [0], np.asarray(d4, dtype=np.float64).reshape(1, 4), [lm])
+
+
+def test_trig_edge_hunt_exact_mode(pkg):
+    """VERDICT r1 item 10.  A cell index is int((rx + d cos a - ox) / res); the device library's sin / cos may differ from
+    glibc's (CPython's math.cos) in the last bit, which can change the index only if the quotient sits within ~1e-12 of an
+    integer.  Hunt for such inputs and show that exact mode (qs_config.exact_trig, default) gives the oracle's cells:
+      1. structured streams -- yaw multiples of 15 degrees, poses on the cell lattice, centimetre distances -- on grids whose
+         origin is 0 or small (the subtraction of a large origin would absorb a last-bit difference);
+      2. crafted geometries: for random rays the grid origin is placed so that the HOST quotient is an integer, or the
+         double just below one -- any last-bit difference on the device flips the cell;
+      3. 2^17 random packets at 5 mm resolution (480 cells per ray, ~1e8 cell decisions).
+    With exact_trig = 0 the same inputs are run for the record (flips are counted and printed, not asserted)."""
+    P = pkg.protocol
+    rng = np.random.default_rng(99)
+    flips_off, edges = 0, 0
+    # -- 1. structured
+    yaws = np.radians(np.arange(24) * 15.0).astype(np.float32)
+    lat = np.arange(-6, 7) * 0.05
+    xs, ys, yw = np.meshgrid(lat, lat, yaws, indexing="ij")
+    n = xs.size
+    dist = (rng.integers(3, 125, (n, 4)) * 0.01)                      # whole centimetres, like the firmware's median filter
+    stream = P.pack_packets(np.ones(n, dtype=int), xs.ravel(), ys.ravel(), yw.ravel(), np.zeros(n, dtype=int), np.zeros(n, dtype=int),
+                            dist, np.zeros(n, dtype=int))
+    for ox in (0.0, -0.8, -1.6, -3.2):
+        o = orc.OracleMapper(64, 0.05, ox, ox, 0.0); o.feed_stream(stream)
+        for mode in (1, 2):
+            with pkg.QuasarMapper(64, 0.05, ox, ox, raycast_mode=mode) as m:
+                m.ingest_array(stream)
+                assert (m.grid_i8() == o.grid).all(), (ox, mode)
+                h, mi = m.counts()
+                assert (h == o.hits).all() and (mi == o.misses).all()
+                edges += m.counters()["edge_rays"]
+        with pkg.QuasarMapper(64, 0.05, ox, ox, exact_trig=False) as m:
+            m.ingest_array(stream)
+            flips_off += int((m.grid_i8() != o.grid).sum())
+    assert edges > 0                                                   # the structured inputs DO land on cell boundaries
+    # -- 2. crafted: one ray per geometry, the host quotient on / just under an integer
+    import math
+    crafted = 0
+    for case in range(160):
+        yaw = np.float32(rng.uniform(-math.pi, math.pi)); s = int(rng.integers(0, 4))
+        rx, ry = np.float32(rng.uniform(0.3, 1.2)), np.float32(rng.uniform(0.3, 1.2))
+        d = np.float32(rng.uniform(0.2, 1.1))
+        a = float(yaw) + (0.0, math.pi / 2, math.pi, -math.pi / 2)[s]
+        ex = float(rx) + float(d) * math.cos(a)
+        k = int(rng.integers(20, 40))
+        ox = ex - k * 0.05
+        for _ in range(64):                                            # walk ox until int((ex - ox) / 0.05) changes at the next double
+            if int((ex - ox) / 0.05) >= k:
+                ox = np.nextafter(ox, np.inf)
+            else:
+                break
+        ox = float(np.nextafter(ox, -np.inf)) if case % 2 else float(ox)   # quotient == k exactly / the double just below k
+        d4 = [0.0, 0.0, 0.0, 0.0]; d4[s] = float(d)
+        pkt = _one_packet(P, float(rx), float(ry), float(yaw), d4)
+        o = orc.OracleMapper(64, 0.05, ox, -0.4, 0.0); o.feed_stream(pkt)
+        with pkg.QuasarMapper(64, 0.05, ox, -0.4) as m:
+            m.ingest_array(pkt)
+            assert (m.grid_i8() == o.grid).all(), case
+            crafted += m.counters()["edge_rays"]
+        with pkg.QuasarMapper(64, 0.05, ox, -0.4, exact_trig=False) as m:
+            m.ingest_array(pkt)
+            flips_off += int((m.grid_i8() != o.grid).sum())
+    assert crafted >= 100                                              # the crafted rays were recognised as edge rays
+    # -- 3. volume: random packets, fine resolution
+    stream = pkg_replay_adversarial(pkg, 1 << 17, 7)
+    o = orc.OracleMapper(2048, 0.005, -5.12, -5.12, 0.0); o.feed_stream(stream)
+    with pkg.QuasarMapper(2048, 0.005, -5.12, -5.12) as m:
+        m.ingest_array(stream)
+        assert (m.grid_i8() == o.grid).all()
+        h, mi = m.counts()
+        assert (h == o.hits).all() and (mi == o.misses).all()
+        assert m.counters()["cells"] == o.n_cells_written
+    print(f"\n[trig-edge hunt] edge rays resolved on the host: structured {edges}, crafted {crafted}; "
+          f"cells differing from the oracle with exact_trig=0: {flips_off}")
+
+
+def pkg_replay_adversarial(pkg, n, seed):
+    import importlib
+    replay = importlib.import_module(pkg.__name__ + ".replay")
+    return replay.adversarial_stream(n, seed=seed, lo=-4.0, hi=4.0)
