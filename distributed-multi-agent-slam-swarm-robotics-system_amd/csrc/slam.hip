@@ -236,7 +236,7 @@ __device__ inline void chain_insert_lanes(const QsGraphDev &G, bool inw, int ran
         lm_x[log_slot] = x; lm_y[log_slot] = y; lm_idx[log_slot] = idx; lm_type[log_slot] = (unsigned char)type;
     }
     const bool inb = inw && kb >= 0;                              // the centre bucket exists
-    const long long key = inb ? kb : -1;
+    const unsigned int key = inb ? (unsigned int)kb : 0xffffffffu;   // (directory entries number well below 2^32)
     const bool is_misc = inw && !inb;
     {
         const unsigned long long mm = __ballot(is_misc);
@@ -251,22 +251,26 @@ __device__ inline void chain_insert_lanes(const QsGraphDev &G, bool inw, int ran
     int ldr = lane;
     for (unsigned long long rem = __ballot(inb); rem;) {
         const int ld = __ffsll((long long)rem) - 1;
-        const long long kk = rl64(key, ld);
+        const unsigned int kk = (unsigned int)__builtin_amdgcn_readlane((int)key, ld);
         const unsigned long long grp = __ballot(inb && key == kk);
         if (inb && key == kk) { grank = (unsigned int)__popcll(grp & ((1ull << lane) - 1)); gsize = (unsigned int)__popcll(grp); ldr = ld; }
         rem &= ~grp;
     }
     // an empty bucket's tail is its first node, the one that belongs to the directory entry
-    const unsigned int tail = de.head ? de.tail : 1u + (unsigned int)key;
+    const unsigned int tail = de.head ? de.tail : 1u + key;
     const unsigned int tc = de.head ? de.tail_cnt : 0u;
     const unsigned int total = tc + gsize;
     const unsigned int nn = (inb && total > QS_NODE_CAP) ? (total - QS_NODE_CAP + QS_NODE_CAP - 1) / QS_NODE_CAP : 0;   // new pool nodes
     // pool nodes are handed out bucket by bucket, in the order of the buckets' first events
     const unsigned int mine = (inb && ldr == lane) ? nn : 0u;
+    // (a bucket needs a new pool node once in seven landmarks: most windows need none, and skip the scan)
+    const bool any_new = __ballot(mine != 0) != 0;
     unsigned int incl = mine;
-    #pragma unroll
-    for (int off = 1; off < QS_WAVE; off <<= 1) { const unsigned int v = __shfl_up(incl, off); if (lane >= off) incl += v; }
-    const unsigned int base = __shfl(pool + incl - mine, ldr);
+    if (any_new) {
+        #pragma unroll
+        for (int off = 1; off < QS_WAVE; off <<= 1) { const unsigned int v = __shfl_up(incl, off); if (lane >= off) incl += v; }
+    }
+    const unsigned int base = any_new ? __shfl(pool + incl - mine, ldr) : pool;
     if (inb && (long long)base + nn <= G.node_cap) {
         const unsigned int p = tc + grank;
         const unsigned int nd = p < QS_NODE_CAP ? tail : base + (p - QS_NODE_CAP) / QS_NODE_CAP;
@@ -275,7 +279,7 @@ __device__ inline void chain_insert_lanes(const QsGraphDev &G, bool inw, int ran
         np->idx[sl] = idx; np->x[sl] = x; np->y[sl] = y;
         if (ldr == lane) {
             QsDirEntry upd;
-            upd.head = 1u + (unsigned int)key; upd.tail = tail; upd.tail_cnt = total; upd.pad = 0;
+            upd.head = 1u + key; upd.tail = tail; upd.tail_cnt = total; upd.pad = 0;
             if (nn) {
                 for (unsigned int q = 0; q + 1 < nn; q++) nd_next[base + q] = base + q + 1;
                 nd_next[tail] = base;
@@ -285,7 +289,7 @@ __device__ inline void chain_insert_lanes(const QsGraphDev &G, bool inw, int ran
             dir[key].head = upd.head; dir[key].tail = upd.tail; dir[key].tail_cnt = upd.tail_cnt; dir[key].pad = 0;
         }
     }
-    pool += __shfl(incl, QS_WAVE - 1);
+    if (any_new) pool += __shfl(incl, QS_WAVE - 1);
     n_lms += k;
 }
 
@@ -334,21 +338,41 @@ __device__ inline long long wave_min_nonneg_i64(long long v)
 
 // the window at the head of the events: the next events whose node index is < first + win (a
 // contiguous prefix of the lanes).  Every role computes it for itself from the same LDS arrays.
-struct ChWindow { long long v_idx, first; double px, py; int v_a, type, k; bool have, v_inw; };
-__device__ inline ChWindow chain_window(const long long *nidx, const int *na, bool active, unsigned int e, unsigned int e1,
-                                        int lane, int win, const int *ntype = nullptr, const double *npx = nullptr,
-                                        const double *npy = nullptr)
+// The window itself (which of the next events have a node index < first + win: a contiguous prefix; how many) depends on
+// the events' node indices alone, so the fetch wave works it out one phase AHEAD, off the decisions' critical path: an
+// event outside the window carries agent -1 in n_a, and the window's size is one LDS word (s_wk).  The roles only read.
+struct ChWindow { long long v_idx; double px, py; int v_a, type, k; bool v_inw; };
+// (every LDS word is read unconditionally by lanes 0..31 and masked afterwards: ONE round trip for the phase's inputs)
+__device__ inline ChWindow chain_window(const long long *nidx, const int *na, const int *wk, bool active, int lane,
+                                        const int *ntype = nullptr, const double *npx = nullptr, const double *npy = nullptr)
 {
     ChWindow w;
-    w.have = active && lane < 32 && e + lane < e1;
-    w.v_idx = w.have ? nidx[lane] : LL_MAX;
-    w.v_a = w.have ? na[lane] : 0;
-    w.type = (ntype && w.have) ? ntype[lane] : 0;                 // (one LDS round trip for all the lane's event data)
-    w.px = (npx && w.have) ? npx[lane] : 0; w.py = (npy && w.have) ? npy[lane] : 0;
-    w.first = rl64(w.v_idx, 0);
-    w.v_inw = w.have && w.v_idx - w.first < win;
-    w.k = __popcll(__ballot(w.v_inw));
+    const int l = lane & 31;
+    const int a = na[l], k = *wk;
+    const long long idx = nidx ? nidx[l] : 0;
+    const int ty = ntype ? ntype[l] : 0;
+    const double x = npx ? npx[l] : 0, y = npy ? npy[l] : 0;
+    w.v_inw = active && lane < 32 && a >= 0;
+    w.v_idx = w.v_inw ? idx : LL_MAX;
+    w.v_a = w.v_inw ? a : 0;
+    w.type = w.v_inw ? ty : 0;
+    w.px = w.v_inw ? x : 0; w.py = w.v_inw ? y : 0;
+    w.k = active ? k : 0;
     return w;
+}
+// fetch wave: 32 events from position q0 on, laid out as the window that starts there
+__device__ inline void chain_fetch(const QsSlamBatch &sb, unsigned int q0, unsigned int e1, int lane, int win, long long *nidx, int *na,
+                                   int *ntype, double *npx, double *npy, int *wk)
+{
+    const unsigned int q = q0 + lane;
+    long long f_idx = LL_MAX; int f_a = 0, f_type = 0; double f_px = 0, f_py = 0;
+    const bool have = lane < 32 && q < e1;
+    if (have) { f_idx = sb.ev_node[q]; f_a = sb.ev_agent[q]; f_type = sb.ev_type[q]; f_px = sb.ev_px[q]; f_py = sb.ev_py[q]; }
+    const long long first = rl64(f_idx, 0);
+    const bool inw = have && f_idx - first < win;
+    const int k = __popcll(__ballot(inw));
+    if (lane < 32) { nidx[lane] = f_idx; na[lane] = inw ? f_a : -1; ntype[lane] = f_type; npx[lane] = f_px; npy[lane] = f_py; }
+    if (lane == 0) *wk = k;
 }
 
 // One workgroup per pose graph, one role per wave, one phase per window, one barrier per phase.  Each role
@@ -395,10 +419,15 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
     __shared__ long long n_idx[2][32];          // events of the current window / the one after it (by parity)
     __shared__ double n_px[2][32], n_py[2][32];
     __shared__ int n_a[2][32], n_type[2][32];
-    __shared__ long long i_idx[2][32];                // a window's landmarks (by window parity): node index, type (wave 0),
-    __shared__ double i_x[2][32], i_y[2][32];         // pose (each agent's owner).  Final at the end of the window's phase; read by the next
-    __shared__ int i_type[2][32];                     // window's queries and moved into the index by wave CH_INS
-    __shared__ int s_ik[2];
+    // A window's landmarks -- node index, type (wave 0), pose (each agent's owner) -- in a ring of three slots: window V is
+    // final at the end of phase V, is moved into the index by wave CH_INS during phase V + 1 (its stores may still be in
+    // flight during phase V + 2), and is read from here by the queries of windows V + 1 and V + 2; slot V % 3 is free again
+    // in phase V + 3.
+    __shared__ long long i_idx[3][32];
+    __shared__ double i_x[3][32], i_y[3][32];
+    __shared__ int i_type[3][32];
+    __shared__ int s_ik[3];
+    __shared__ int s_wk[2];                           // size of the window whose events are in n_*[parity]
     __shared__ long long s_nmisc;
 
     for (int t = tid; t < nb; t += CH_THREADS) {
@@ -407,27 +436,33 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
         s_lastc[0][t] = last_closure[bot0 + t];
         s_acnt[t] = sb.agent_ev[bot0 + t];             // where the agent's next closure record goes
     }
-    if (tid == 0) { s_nmisc = Gp->n_misc; s_ik[0] = 0; s_ik[1] = 0; }
-    if (tid < 64) {
+    if (tid == 0) { s_nmisc = Gp->n_misc; s_ik[0] = 0; s_ik[1] = 0; s_ik[2] = 0; }
+    if (tid < 96) {
         const int h = tid >> 5, t = tid & 31;
-        i_idx[h][t] = LL_MAX; i_x[h][t] = 0; i_y[h][t] = 0; i_type[h][t] = 0; w_ridx[h][t] = LL_MAX;
+        i_idx[h][t] = LL_MAX; i_x[h][t] = 0; i_y[h][t] = 0; i_type[h][t] = 0;
+        if (h < 2) w_ridx[h][t] = LL_MAX;
     }
 
     const unsigned int e0 = sb.ev_base[g], e1 = sb.ev_base[g + 1];
 
-    if (wave == CH_FETCH && lane < 32) {
-        const bool have = e0 + lane < e1;
-        n_idx[0][lane] = have ? sb.ev_node[e0 + lane] : LL_MAX;
-        n_a[0][lane] = have ? sb.ev_agent[e0 + lane] : 0; n_type[0][lane] = have ? sb.ev_type[e0 + lane] : 0;
-        n_px[0][lane] = have ? sb.ev_px[e0 + lane] : 0; n_py[0][lane] = have ? sb.ev_py[e0 + lane] : 0;
-    }
+    if (wave == CH_FETCH) chain_fetch(sb, e0, e1, lane, win, n_idx[0], n_a[0], n_type[0], n_px[0], n_py[0], &s_wk[0]);
     __syncthreads();
 
     unsigned int e = e0;
-    int par = 0;
+    int par = 0, ring = 0;                       // window parity (events, states, results), window number mod 3 (landmark slots)
     bool have_prev = false;
+#define CH_R1 (ring == 0 ? 2 : ring - 1)       // slot of window V - 1
+#define CH_R2 (ring == 2 ? 0 : ring + 1)       // slot of window V - 2
 // what every role does at the end of a phase
-#define CH_PHASE_END(active_, k_)  lds_barrier(); e += (k_); have_prev = (active_); if (active_) par ^= 1
+#ifdef QS_CHAIN_PROF3
+#define CH_P3_DECL unsigned long long p3_busy = 0, p3_t = __builtin_amdgcn_s_memtime()
+#define CH_PHASE_END(active_, k_)  p3_busy += __builtin_amdgcn_s_memtime() - p3_t; lds_barrier(); p3_t = __builtin_amdgcn_s_memtime(); e += (k_); have_prev = (active_); if (active_) { par ^= 1; ring = ring == 2 ? 0 : ring + 1; }
+#define CH_P3_REPORT(slot_) if (lane == 0) atomicAdd(&counters[slot_], p3_busy)
+#else
+#define CH_P3_DECL
+#define CH_PHASE_END(active_, k_)  lds_barrier(); e += (k_); have_prev = (active_); if (active_) { par ^= 1; ring = ring == 2 ? 0 : ring + 1; }
+#define CH_P3_REPORT(slot_)
+#endif
 
     if (wave == 0) {
         // =================================== wave 0: commit + prepare ===================================
@@ -443,11 +478,12 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
         int a = 0;
         double x = 0, y = 0;
         bool inw = false;
+        CH_P3_DECL;
         for (;;) {
             const bool active = e < e1;
             if (!active && !have_prev) break;
             const unsigned long long ta0 = __builtin_amdgcn_s_memtime();
-            const ChWindow W = chain_window(n_idx[par], n_a[par], active, e, e1, lane, win, n_type[par], n_px[par], n_py[par]);
+            const ChWindow W = chain_window(n_idx[par], n_a[par], &s_wk[par], active, lane, n_type[par], n_px[par], n_py[par]);
             if (have_prev) {
                 // ---- closure records of window V - 1, in node order ----
                 const long long m_idx = lane < 32 ? w_ridx[par ^ 1][lane] : LL_MAX;
@@ -480,8 +516,8 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
                 if (!inw) a = 0;
                 x = raw_pose ? W.px : W.px + s_dx[par][a];              // rx += cdx  :856
                 y = raw_pose ? W.py : W.py + s_dy[par][a];              // ry += cdy  :857
-                if (lane < 32) { i_idx[par][lane] = inw ? idx : LL_MAX; i_type[par][lane] = inw ? W.type : 0; }
-                if (lane == 0) s_ik[par] = W.k;
+                if (lane < 32) { i_idx[ring][lane] = inw ? idx : LL_MAX; i_type[ring][lane] = inw ? W.type : 0; }
+                if (lane == 0) s_ik[ring] = W.k;
                 st_windows++;
             } else {
                 inw = false;
@@ -492,9 +528,10 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
         if (lane == 0) {
             atomicAdd(&counters[QS_CNT_CLOSURES], (unsigned long long)(n_cls - n_cls0));
             atomicAdd(&counters[QS_CNT_SLAM_WINDOWS], st_windows);
-#ifndef QS_CHAIN_PROF
+#if !defined(QS_CHAIN_PROF) && !defined(QS_CHAIN_PROF2) && !defined(QS_CHAIN_PROF3)
             atomicAdd(&counters[QS_CNT_SLAM_CYC_A], st_a); atomicAdd(&counters[QS_CNT_SLAM_CYC_B], st_b);
 #endif
+            CH_P3_REPORT(QS_CNT_SLAM_CYC_A);
             atomicAdd(&counters[QS_CNT_SLAM_CYCLES], __builtin_amdgcn_s_memtime() - t0_cyc);
             atomicAdd(&counters[QS_CNT_SLAM_REALTIME], __builtin_amdgcn_s_memrealtime() - t0_real);
             Gp->n_nodes = Gp->n_nodes + sb.acc_total[g];
@@ -503,38 +540,37 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
         for (int t = lane; t < nb; t += QS_WAVE) sb.acl_cnt[bot0 + t] = s_acnt[t] - sb.agent_ev[bot0 + t];
     } else if (wave == CH_FETCH) {
         // =================================== wave CH_FETCH: event fetch ===================================
+        CH_P3_DECL;
         for (;;) {
             const bool active = e < e1;
             if (!active && !have_prev) break;
-            const ChWindow W = chain_window(n_idx[par], n_a[par], active, e, e1, lane, win);
-            if (lane < 32 && active) {
-                const unsigned int q = e + W.k + lane;
-                long long f_idx = LL_MAX; int f_a = 0, f_type = 0; double f_px = 0, f_py = 0;
-                if (q < e1) { f_idx = sb.ev_node[q]; f_a = sb.ev_agent[q]; f_type = sb.ev_type[q]; f_px = sb.ev_px[q]; f_py = sb.ev_py[q]; }
-                n_idx[par ^ 1][lane] = f_idx; n_a[par ^ 1][lane] = f_a; n_type[par ^ 1][lane] = f_type;
-                n_px[par ^ 1][lane] = f_px; n_py[par ^ 1][lane] = f_py;
-            }
-            CH_PHASE_END(active, W.k);
+            const int k = active ? s_wk[par] : 0;
+            if (active) chain_fetch(sb, e + k, e1, lane, win, n_idx[par ^ 1], n_a[par ^ 1], n_type[par ^ 1], n_px[par ^ 1], n_py[par ^ 1], &s_wk[par ^ 1]);
+            CH_PHASE_END(active, k);
         }
+        CH_P3_REPORT(QS_CNT_SLAM_CYC_B);
     } else if (wave == CH_INS) {
         // =================================== wave CH_INS: index insert ===================================
         const QsGraphDev G = *Gp;
         long long n_lms = G.n_lms, n_misc = G.n_misc;
         unsigned int pool = G.nodes_used;
+        CH_P3_DECL;
         for (;;) {
             const bool active = e < e1;
             if (!active && !have_prev) break;
-            const ChWindow W = chain_window(n_idx[par], n_a[par], active, e, e1, lane, win);
+            const int k = active ? s_wk[par] : 0;
+            // the stores of the insert one phase ago have had that whole phase: they are done by now (the queries of THIS
+            // phase still see that window in LDS, the next phase's only in the index), and the side list's new length shows
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0 && s_nmisc != n_misc) s_nmisc = n_misc;
             if (have_prev) {
-                if (s_ik[par ^ 1] > 0) {
-                    chain_insert_window(G, bg, i_idx[par ^ 1], i_x[par ^ 1], i_y[par ^ 1], i_type[par ^ 1], s_ik[par ^ 1], lane,
-                                        n_lms, n_misc, pool);
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the stores are done before the phase ends ...
-                    if (lane == 0) s_nmisc = n_misc;                         // ... and before the side list's new length shows
-                }
+                const int r1 = CH_R1;
+                if (s_ik[r1] > 0)
+                    chain_insert_window(G, bg, i_idx[r1], i_x[r1], i_y[r1], i_type[r1], s_ik[r1], lane, n_lms, n_misc, pool);
             }
-            CH_PHASE_END(active, W.k);
+            CH_PHASE_END(active, k);
         }
+        CH_P3_REPORT(QS_CNT_SLAM_CYC_C);
         if (lane == 0) {
             atomicAdd(&counters[QS_CNT_LANDMARKS], (unsigned long long)(n_lms - G.n_lms));
             Gp->n_lms = n_lms;
@@ -549,7 +585,8 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
         const int own = (wave - 1) + CH_AGW * lane;
         double c_dx = 0, c_dy = 0;
         long long c_last = 0;
-        if (own < nb) { c_dx = s_dx[0][own]; c_dy = s_dy[0][own]; c_last = s_lastc[0][own]; }
+        if (ONE) { c_dx = s_dx[0][wave - 1]; c_dy = s_dy[0][wave - 1]; c_last = s_lastc[0][wave - 1]; }     // one agent: every lane holds its state
+        else if (own < nb) { c_dx = s_dx[0][own]; c_dy = s_dy[0][own]; c_last = s_lastc[0][own]; }
         const QsNodeG g_nodes = (QsNodeG)Gp->nodes;
         const QsU32G g_next = (QsU32G)Gp->nd_next;
         // lane = (bucket of the 3x3 neighbourhood, entry of that bucket's current 7-entry node): a node
@@ -557,34 +594,52 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
         const int nbk = lane / QS_NODE_CAP, se = lane % QS_NODE_CAP;
         const int last_lane = min(nbk * QS_NODE_CAP + QS_NODE_CAP - 1, 63);
         const int nb_dx = (nbk % 3) - 1, nb_dy = (nbk / 3) - 1;        // the lane's neighbour of the 3x3
-        unsigned long long st_rounds = 0, st_iters = 0, st_misc = 0;
+        unsigned long long st_misc = 0;            // side-list scans (rare path; the tests read it)
+#ifdef QS_CHAIN_STATS
+        unsigned long long st_rounds = 0, st_iters = 0;
+#define CH_STAT(x) (x)++
+#else
+#define CH_STAT(x) do { } while (0)
+#endif
 #ifdef QS_CHAIN_PROF
         unsigned long long pq_a = 0, pq_b = 0, pq_c = 0;
+#endif
+        CH_P3_DECL;
+#ifdef QS_CHAIN_PROF2
+        unsigned long long p2_head = 0, p2_setup = 0, p2_scan = 0, p2_post = 0, p2_pub = 0, p2_bar = 0, p2_t4 = __builtin_amdgcn_s_memtime();
 #endif
         for (;;) {
             const bool active = e < e1;
             if (!active && !have_prev) break;
-            const ChWindow W = chain_window(n_idx[par], n_a[par], active, e, e1, lane, win, n_type[par], n_px[par], n_py[par]);
+#ifdef QS_CHAIN_PROF2
+            const unsigned long long p2_t0 = __builtin_amdgcn_s_memtime();
+            p2_bar += p2_t0 - p2_t4;
+#endif
             // window V - 1 is not in the index yet: its landmarks (final poses) are in LDS, in node order.  Read in
             // the same LDS round trip as the events, looked at in the shadow of a query's first node loads.
-            long long li = LL_MAX; double lx = 0, ly = 0; int lt = 0;
-            if (lane < 32) { li = i_idx[par ^ 1][lane]; lx = i_x[par ^ 1][lane]; ly = i_y[par ^ 1][lane]; lt = i_type[par ^ 1][lane]; }
+            const int lsl = lane < 32 ? CH_R2 : CH_R1;                     // lanes 0..31: window V - 2, lanes 32..63: window V - 1 (node order)
+            const long long li = i_idx[lsl][lane & 31]; const double lx = i_x[lsl][lane & 31], ly = i_y[lsl][lane & 31]; const int lt = i_type[lsl][lane & 31];
             const long long nm = s_nmisc;
-            const double o_dx = rlf64(c_dx, 0), o_dy = rlf64(c_dy, 0);     // lane 0's agent: drift at window start
+            const ChWindow W = chain_window(n_idx[par], n_a[par], &s_wk[par], active, lane, n_type[par], n_px[par], n_py[par]);
+            const double o_dx = ONE ? c_dx : rlf64(c_dx, 0), o_dy = ONE ? c_dy : rlf64(c_dy, 0);     // lane 0's agent: drift at window start
             const bool ownlane = W.v_inw && (ONE ? W.v_a : W.v_a % CH_AGW) + 1 == wave;
             // the lane's event may close if its agent is past its cool-down (:304); an agent that finds a match in
             // this window takes its later events off the list, so the state at window start decides for all of them
-            const long long lane_last = ONE ? rl64(c_last, 0) : (ownlane ? s_lastc[par][W.v_a] : 0);
+            const long long lane_last = ONE ? c_last : (ownlane ? s_lastc[par][W.v_a] : 0);
             const bool may_close = ownlane && W.v_idx - lane_last >= min_between;
+#ifdef QS_CHAIN_PROF2
+            const unsigned long long p2_t1 = __builtin_amdgcn_s_memtime();
+            p2_head += p2_t1 - p2_t0;
+#endif
             for (unsigned long long qrem = __ballot(may_close); qrem; qrem &= qrem - 1) {
-#ifdef QS_CHAIN_PROF
+#if defined(QS_CHAIN_PROF) || defined(QS_CHAIN_PROF2)
                 const unsigned long long tq0 = __builtin_amdgcn_s_memtime();
 #endif
                 const int src = __ffsll((long long)qrem) - 1;
                 const int qa = __builtin_amdgcn_readlane(W.v_a, src);
                 const int ql = ONE ? 0 : qa / CH_AGW;                               // the lane that keeps agent qa's state
                 const long long qidx = rl64(W.v_idx, src);
-                const double odx = rlf64(c_dx, ql), ody = rlf64(c_dy, ql);
+                const double odx = ONE ? c_dx : rlf64(c_dx, ql), ody = ONE ? c_dy : rlf64(c_dy, ql);
                 const double spx = rlf64(W.px, src), spy = rlf64(W.py, src);
                 const double qx = raw_pose ? spx : spx + odx;                         // rx += cdx  :856
                 const double qy = raw_pose ? spy : spy + ody;                         // ry += cdy  :857
@@ -596,10 +651,10 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
                 if (indexed && lane < 9 * QS_NODE_CAP) node = 1u + (unsigned int)bucket_key(qtype, qcx + nb_dx, qcy + nb_dy, bg);   // the entry's own first node
                 long long best = LL_MAX, gbest = LL_MAX;
                 double bx = 0, by = 0;
-                st_rounds++;
+                CH_STAT(st_rounds);
                 long long l_idx = LL_MAX;
                 double l_x = 0, l_y = 0;
-#ifdef QS_CHAIN_PROF
+#if defined(QS_CHAIN_PROF) || defined(QS_CHAIN_PROF2)
                 const unsigned long long tq1 = __builtin_amdgcn_s_memtime();
 #endif
                 for (bool first_scan = true;; first_scan = false) {
@@ -622,7 +677,7 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
                         }
                     }
                     if (!anyn) break;
-                    st_iters++;
+                    CH_STAT(st_iters);
                     const bool inlim = node != 0 && id <= limit;      // empty slots read as a huge index
                     bool newhit = false;
                     if (inlim && best == LL_MAX) {
@@ -643,7 +698,7 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
                     const bool b_full = ((limm >> last_lane) & 1ull) != 0;
                     if (node) node = (b_hit || !b_full || nxt == 0 || lastid >= gbest) ? 0u : nxt;
                 }
-#ifdef QS_CHAIN_PROF
+#if defined(QS_CHAIN_PROF) || defined(QS_CHAIN_PROF2)
                 const unsigned long long tq2 = __builtin_amdgcn_s_memtime();
 #endif
                 double wx = 0, wy = 0;
@@ -691,37 +746,61 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
                     const double ex = wx - qx, ey = wy - qy;                                   // :311-312
                     const double cdx = ex * corr, cdy = ey * corr;                             // :314-315
                     const double ndx = odx + cdx, ndy = ody + cdy;                             // :911-914
-                    if (lane == ql) { c_dx = ndx; c_dy = ndy; c_last = qidx; }                 // :318
+                    if (ONE || lane == ql) { c_dx = ndx; c_dy = ndy; c_last = qidx; }          // :318
                 }
 #ifdef QS_CHAIN_PROF
                 { const unsigned long long tq3 = __builtin_amdgcn_s_memtime(); pq_a += tq1 - tq0; pq_b += tq2 - tq1; pq_c += tq3 - tq2; }
 #endif
+#ifdef QS_CHAIN_PROF2
+                { const unsigned long long tq3 = __builtin_amdgcn_s_memtime(); p2_setup += tq1 - tq0; p2_scan += tq2 - tq1; p2_post += tq3 - tq2; }
+#endif
             }
-            if (active && own < nb) { s_dx[par ^ 1][own] = c_dx; s_dy[par ^ 1][own] = c_dy; s_lastc[par ^ 1][own] = c_last; }
+#ifdef QS_CHAIN_PROF2
+            const unsigned long long p2_t2 = __builtin_amdgcn_s_memtime();
+#endif
+            if (active && own < nb) { s_dx[par ^ 1][own] = c_dx; s_dy[par ^ 1][own] = c_dy; s_lastc[par ^ 1][own] = c_last; }   // (ONE: lane 0)
             // the window's landmarks get their final pose from their agent's owner: the drift at window start,
             // or -- later events of an agent that closed in this window -- the drift after the closure (:855-857)
             if (ONE) {                                                    // one agent per owner: its state is in lane 0
-                const bool after = W.v_idx > rl64(c_last, 0);
-                const double ddx = after ? rlf64(c_dx, 0) : o_dx, ddy = after ? rlf64(c_dy, 0) : o_dy;
-                if (ownlane) { i_x[par][lane] = raw_pose ? W.px : W.px + ddx; i_y[par][lane] = raw_pose ? W.py : W.py + ddy; }
+                const bool after = W.v_idx > c_last;
+                const double ddx = after ? c_dx : o_dx, ddy = after ? c_dy : o_dy;
+                if (ownlane) { i_x[ring][lane] = raw_pose ? W.px : W.px + ddx; i_y[ring][lane] = raw_pose ? W.py : W.py + ddy; }
             } else if (ownlane) {
                 const int va = W.v_a;
                 const bool after = W.v_idx > s_lastc[par ^ 1][va];        // (own rows of the state, written just above)
                 const double ddx = after ? s_dx[par ^ 1][va] : s_dx[par][va], ddy = after ? s_dy[par ^ 1][va] : s_dy[par][va];
-                i_x[par][lane] = raw_pose ? W.px : W.px + ddx;
-                i_y[par][lane] = raw_pose ? W.py : W.py + ddy;
+                i_x[ring][lane] = raw_pose ? W.px : W.px + ddx;
+                i_y[ring][lane] = raw_pose ? W.py : W.py + ddy;
             }
+#ifdef QS_CHAIN_PROF2
+            p2_t4 = __builtin_amdgcn_s_memtime();
+            p2_pub += p2_t4 - p2_t2;
+#endif
             CH_PHASE_END(active, W.k);
         }
+#ifdef QS_CHAIN_PROF2
+        if (lane == 0 && wave == 1) {
+            atomicAdd(&counters[QS_CNT_SLAM_CYC_A], p2_head); atomicAdd(&counters[QS_CNT_SLAM_CYC_B], p2_setup);
+            atomicAdd(&counters[QS_CNT_SLAM_CYC_C], p2_scan); atomicAdd(&counters[QS_CNT_SLAM_MISC_ITERS], p2_post);
+            atomicAdd(&counters[QS_CNT_EKF_WRAP_CLAMP], p2_pub); atomicAdd(&counters[QS_CNT_SLAM_ROUNDS], p2_bar);
+        }
+#endif
+#ifdef QS_CHAIN_PROF3
+        if (lane == 0) atomicAdd(&counters[wave == 1 ? QS_CNT_SLAM_MISC_ITERS : QS_CNT_EKF_WRAP_CLAMP], p3_busy);
+#endif
         if (own < nb) {
             drift[2 * (bot0 + own)] = c_dx;
             drift[2 * (bot0 + own) + 1] = c_dy;
             last_closure[bot0 + own] = c_last;
         }
         if (lane == 0) {
+#if defined(QS_CHAIN_STATS) && !defined(QS_CHAIN_PROF2)
             atomicAdd(&counters[QS_CNT_SLAM_ROUNDS], st_rounds);
             atomicAdd(&counters[QS_CNT_SLAM_NODE_ITERS], st_iters);
-            atomicAdd(&counters[QS_CNT_SLAM_MISC_ITERS], st_misc);
+#endif
+#if !defined(QS_CHAIN_PROF2) && !defined(QS_CHAIN_PROF3)
+            if (st_misc) atomicAdd(&counters[QS_CNT_SLAM_MISC_ITERS], st_misc);
+#endif
 #ifdef QS_CHAIN_PROF
             atomicAdd(&counters[QS_CNT_SLAM_CYC_A], pq_a); atomicAdd(&counters[QS_CNT_SLAM_CYC_B], pq_b); atomicAdd(&counters[QS_CNT_SLAM_CYC_C], pq_c);
 #endif
