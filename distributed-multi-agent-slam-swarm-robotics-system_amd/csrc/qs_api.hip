@@ -174,6 +174,8 @@ static int reset_state(qs_ctx *c)
     HIPCHK(c, qs_launch_slam_reset_index(c));
     for (int g = 0; g < c->n_graphs; g++) { c->lms_upper[g] = 0; c->cls_upper[g] = 0; }
     c->next_seq = 0; c->epoch_base = 0; c->last_n = 0; c->last_has_poses = false; c->n_rebases = 0; c->edge_rays_total = 0;
+    c->pile_mode = false;
+    HIPCHK(c, hipMemsetAsync(c->d_flags, 0, 2 * sizeof(unsigned int), c->stream));
     return QS_OK;
 }
 
@@ -231,6 +233,8 @@ extern "C" int qs_create(const qs_config *cfg, qs_ctx **out)
     CREATE_CHK(hipMalloc((void **)&c->d_graph_batch, (size_t)c->n_graphs * 2 * sizeof(unsigned long long)));
     CREATE_CHK(hipMalloc((void **)&c->d_ekf, (size_t)nb * 44 * sizeof(double)));
     CREATE_CHK(hipMalloc((void **)&c->d_ekf_prev, (size_t)nb * 4 * sizeof(double)));
+    CREATE_CHK(hipMalloc((void **)&c->d_flags, 2 * sizeof(unsigned int)));
+    CREATE_CHK(hipMemset(c->d_flags, 0, 2 * sizeof(unsigned int)));
     CREATE_CHK(hipMalloc((void **)&c->d_graphs, (size_t)c->n_graphs * sizeof(QsGraphDev)));
     CREATE_CHK(hipMemset(c->d_graphs, 0, (size_t)c->n_graphs * sizeof(QsGraphDev)));
     c->h_graphs.assign(c->n_graphs, QsGraphDev{});
@@ -256,7 +260,7 @@ static void free_batch(qs_ctx *c)
     hipFree(b.accept); hipFree(b.agent); hipFree(b.lm); hipFree(b.px); hipFree(b.py); hipFree(b.yaw);
     hipFree(b.dist); hipFree(b.enc); hipFree(b.rx); hipFree(b.ry); hipFree(b.hit); hipFree(b.hit_valid);
     if (b.map_ok != b.accept) hipFree(b.map_ok);
-    hipFree(b.edge); hipFree(b.edge_n);
+    hipFree(b.edge);
     memset(&b, 0, sizeof b);
     QsSlamBatch &sb = c->sb;
     hipFree(sb.node); hipFree(sb.ev_node); hipFree(sb.ev_agent); hipFree(sb.ev_type); hipFree(sb.ev_px); hipFree(sb.ev_py);
@@ -275,7 +279,7 @@ extern "C" int qs_destroy(qs_ctx *c)
     free_batch(c);
     hipFree(c->d_stamps); hipFree(c->d_counts); hipFree(c->d_counts_fused); hipFree(c->d_io_ws); hipFree(c->d_offset); hipFree(c->d_drift);
     hipFree(c->d_last_closure); hipFree(c->d_zone); hipFree(c->d_counters); hipFree(c->d_graph_batch);
-    hipFree(c->d_ekf); hipFree(c->d_ekf_prev); hipFree(c->d_ekf_ws); hipFree(c->d_graphs); hipFree(c->d_pkts); hipFree(c->d_lens);
+    hipFree(c->d_ekf); hipFree(c->d_ekf_prev); hipFree(c->d_ekf_ws); hipFree(c->d_graphs); hipFree(c->d_flags); hipFree(c->d_pkts); hipFree(c->d_lens);
     hipFree(c->d_time); hipFree(c->d_bin_ws); hipFree(c->d_frontier_ws);
     for (auto &p : c->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (auto e : c->ev_pool) hipEventDestroy(e);
@@ -372,7 +376,7 @@ static int ensure_batch(qs_ctx *c, size_t n)
         b.own_lo = c->cfg.shard_rank * c->cfg.shard_bots + 1;
         b.own_hi = std::min(c->cfg.max_agent, (c->cfg.shard_rank + 1) * c->cfg.shard_bots);
     } else { b.map_ok = b.accept; b.own_lo = 1; b.own_hi = c->cfg.max_agent; }
-    if (c->cfg.exact_trig) { HIPCHK(c, dev_realloc(&b.edge, 4 * cap)); if (!b.edge_n) HIPCHK(c, hipMalloc((void **)&b.edge_n, sizeof(unsigned int))); }
+    if (c->cfg.exact_trig) { HIPCHK(c, dev_realloc(&b.edge, 4 * cap)); b.edge_n = c->d_flags; }
     QsSlamBatch &sb = c->sb;
     const size_t nblk = (size_t)qs_slam_blocks(cap), G = (size_t)c->n_graphs, nb = (size_t)c->cfg.max_agent + 2;
     HIPCHK(c, dev_realloc(&sb.node, cap)); HIPCHK(c, dev_realloc(&sb.ev_node, cap));
@@ -484,9 +488,11 @@ static int io_reserve(qs_ctx *c, size_t bytes);
 // ingest would have given them.  Costs one 4-byte read-back per ingest (the call then ends with a stream sync).
 static int resolve_edge_rays(qs_ctx *c, uint64_t seq0)
 {
-    unsigned int n_edge = 0;
-    HIPCHK(c, hipMemcpyAsync(&n_edge, c->b.edge_n, sizeof n_edge, hipMemcpyDeviceToHost, c->stream));
+    unsigned int fl[2] = {0, 0};
+    HIPCHK(c, hipMemcpyAsync(fl, c->d_flags, sizeof fl, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    const unsigned int n_edge = fl[0];
+    if (fl[1]) c->pile_mode = true;                      // a landmark pile has formed: the chain kernel's DENSE variant from now on
     c->edge_rays_total += n_edge;
     if (n_edge == 0) return QS_OK;
     const size_t bytes = (size_t)n_edge * 5 * sizeof(double);
@@ -513,6 +519,17 @@ static int resolve_edge_rays(qs_ctx *c, uint64_t seq0)
     HIPCHK(c, hipMemcpyAsync(d, h.data(), bytes, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, qs_launch_edge_cast(c, n_edge, d, seq0));
     HIPCHK(c, hipStreamSynchronize(c->stream));                                                // h goes out of scope
+    return QS_OK;
+}
+
+// at a point where the stream is synchronised anyway: has a landmark pile formed (slam.hip, DENSE)?
+static int read_pile_flag(qs_ctx *c)
+{
+    if (c->pile_mode) return QS_OK;
+    unsigned int f = 0;
+    HIPCHK(c, hipMemcpyAsync(&f, c->d_flags + 1, sizeof f, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (f) c->pile_mode = true;
     return QS_OK;
 }
 
@@ -602,6 +619,7 @@ extern "C" int qs_ingest(qs_ctx *c, const uint8_t *pkts, size_t n, size_t stride
     HIPCHK(c, hipMemcpyAsync(cur.data(), c->d_graphs, cur.size() * sizeof(QsGraphDev), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (int g = 0; g < c->n_graphs; g++) { c->lms_upper[g] = cur[g].n_lms; c->cls_upper[g] = cur[g].n_cls; }
+    if (!c->cfg.exact_trig) return read_pile_flag(c);
     return QS_OK;
 }
 
@@ -882,6 +900,8 @@ extern "C" int qs_slam_add_poses(qs_ctx *c, const double *x, const double *y, co
     std::vector<long long> node(n);
     HIPCHK(c, hipMemcpyAsync(node.data(), c->sb.node, n * sizeof(long long), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    rc = read_pile_flag(c);
+    if (rc != QS_OK) return rc;
     c->last_has_poses = false;
     if (closed) memset(closed, 0, n);
     if (corr2) for (size_t i = 0; i < 2 * n; i++) corr2[i] = 0.0;

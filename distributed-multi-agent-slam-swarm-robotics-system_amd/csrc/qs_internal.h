@@ -156,6 +156,8 @@ struct qs_ctx {
     void *d_ekf_ws = nullptr; size_t ekf_ws_bytes = 0;   // parallel-in-time EKF workspace (ekf_scan.hip)
 
     uint64_t next_seq = 0, epoch_base = 0, n_rebases = 0;
+    unsigned int *d_flags = nullptr;             // [0] edge rays of the batch (exact-trig mode), [1] a landmark pile has formed (slam.hip, DENSE)
+    bool pile_mode = false;                      // launch the chain kernel's DENSE variant
     uint64_t edge_rays_total = 0;                // exact-trig mode: rays resolved on the host since the last reset
 
     // timing

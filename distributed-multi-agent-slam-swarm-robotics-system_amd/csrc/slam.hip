@@ -155,6 +155,7 @@ qs_slam_index_kernel(size_t n, QsBatch b, QsSlamBatch sb, const QsGraphDev *__re
 // ONE chain of closure decisions (each shapes the landmarks the next may match), so what counts is the
 // number of instructions and LDS / memory round trips between one decision and the next.
 #define CH_WAVES 16
+#define CH_PILE_NODES 64             // a bucket chain of more pool nodes than this is a pile (see qs_slam_chain_kernel, DENSE)
 #define CH_THREADS (CH_WAVES * QS_WAVE)
 // (waves go to the four SIMDs round robin: with <= 2 owners the insert wave has SIMD 3 to itself, the light
 // fetch wave shares SIMD 2 with owner 2 -- the other way round costs 2 %)
@@ -221,7 +222,7 @@ typedef const QS_GLOBAL unsigned int *QsU32G;
 // the lane's position among them).  Appends to the reference's insertion-ordered log and to the bucket
 // chains; events of one bucket are appended in lane (= node) order.
 __device__ inline void chain_insert_lanes(const QsGraphDev &G, bool inw, int rank, long long idx, long long kb, double x, double y,
-                                          int type, int k, int lane, long long &n_lms, long long &n_misc, unsigned int &pool)
+                                          int type, int k, int lane, long long &n_lms, long long &n_misc, unsigned int &pool, bool &pile)
 {
     // (global address space: the graph's pointers come out of a struct in memory and would be FLAT otherwise)
     QS_GLOBAL double *const lm_x = (QS_GLOBAL double *)G.lm_x, *const lm_y = (QS_GLOBAL double *)G.lm_y;
@@ -244,7 +245,7 @@ __device__ inline void chain_insert_lanes(const QsGraphDev &G, bool inw, int ran
         n_misc += __popcll(mm);
     }
     QsDirEntry de = {0, 0, 0, 0};
-    if (inb) { de.head = dir[kb].head; de.tail = dir[kb].tail; de.tail_cnt = dir[kb].tail_cnt; }
+    if (inb) { de.head = dir[kb].head; de.tail = dir[kb].tail; de.tail_cnt = dir[kb].tail_cnt; de.pad = dir[kb].pad; }
     // the events of one bucket: position among them (lane = node order), how many, who goes first -- the only
     // part that walks the distinct buckets one by one; everything after is lane-parallel
     unsigned int grank = 0, gsize = 0;
@@ -279,17 +280,21 @@ __device__ inline void chain_insert_lanes(const QsGraphDev &G, bool inw, int ran
         np->idx[sl] = idx; np->x[sl] = x; np->y[sl] = y;
         if (ldr == lane) {
             QsDirEntry upd;
-            upd.head = 1u + key; upd.tail = tail; upd.tail_cnt = total; upd.pad = 0;
+            upd.head = 1u + key; upd.tail = tail; upd.tail_cnt = total; upd.pad = de.head ? de.pad + nn : nn;     // pad: pool nodes of this chain
             if (nn) {
                 for (unsigned int q = 0; q + 1 < nn; q++) nd_next[base + q] = base + q + 1;
                 nd_next[tail] = base;
                 upd.tail = base + nn - 1;
                 upd.tail_cnt = total - QS_NODE_CAP * nn;
             }
-            dir[key].head = upd.head; dir[key].tail = upd.tail; dir[key].tail_cnt = upd.tail_cnt; dir[key].pad = 0;
+            dir[key].head = upd.head; dir[key].tail = upd.tail; dir[key].tail_cnt = upd.tail_cnt; dir[key].pad = upd.pad;
         }
     }
-    if (any_new) pool += __shfl(incl, QS_WAVE - 1);
+    if (any_new) {
+        pool += __shfl(incl, QS_WAVE - 1);
+        // the directory entry's spare word counts the chain's pool nodes: a chain past CH_PILE_NODES is a pile
+        pile = pile || __ballot(inb && ldr == lane && nn && de.pad + nn > CH_PILE_NODES) != 0;
+    }
     n_lms += k;
 }
 
@@ -299,14 +304,14 @@ __device__ inline void chain_insert_lanes(const QsGraphDev &G, bool inw, int ran
 // i.e. before the window after next looks for them in HBM.
 __device__ inline void chain_insert_window(const QsGraphDev &G, const QsBucketGeom &bg, const long long *i_idx,
                                            const double *i_x, const double *i_y, const int *i_type, int k, int lane,
-                                           long long &n_lms, long long &n_misc, unsigned int &pool)
+                                           long long &n_lms, long long &n_misc, unsigned int &pool, bool &pile)
 {
     const long long idx = lane < 32 ? i_idx[lane] : LL_MAX;
     const double x = lane < 32 ? i_x[lane] : 0, y = lane < 32 ? i_y[lane] : 0;
     const int type = lane < k ? i_type[lane] : 0;
     int cx, cy;
     const long long kb = bucket_cell(x, y, type, bg, cx, cy) ? bucket_key(type, cx, cy, bg) : -1;   // -1: side list
-    chain_insert_lanes(G, lane < k, lane, idx, kb, x, y, type, k, lane, n_lms, n_misc, pool);
+    chain_insert_lanes(G, lane < k, lane, idx, kb, x, y, type, k, lane, n_lms, n_misc, pool, pile);
 }
 
 // wave-uniform read of one lane of a double
@@ -394,12 +399,20 @@ __device__ inline void chain_fetch(const QsSlamBatch &sb, unsigned int q0, unsig
 // Waves without a role leave at once (a barrier counts the waves still running).
 // ONE: at most CH_AGW bots per graph, i.e. one agent per owner (its state in lane 0): the agent -> owner /
 // lane arithmetic folds away.
-template <bool ONE>
+// DENSE: the variant for graphs that have grown a PILE -- a bucket chain of more than CH_PILE_NODES pool nodes.  A query whose
+// point is next to such a bucket but out of reach of its landmarks, and whose own first match is younger than the pile, walks
+// the whole chain: a dependent node read per 7 entries, the reference's O(L) scan only slower (tools/k4_adversarial.py: 5.8 ms
+// per query at 10^5 entries, 3.6 x the CPU's list scan).  In this variant a query that is still walking after
+// max(8, L / 512) node rounds scans the insertion-ordered landmark LOG instead, 128 entries per coalesced round -- the
+// reference's own loop (:294), a wave wide (0.46 ms per query on the same pile).  The insert wave raises a flag when a chain
+// passes CH_PILE_NODES; the host reads it with the edge-ray count at the end of an ingest and launches this variant from then
+// on.  The plain variant stays as it is: the round counter and the scan cost every query ~100 cycles (3 %) when compiled in.
+template <bool ONE, bool DENSE>
 __global__ void __launch_bounds__(CH_THREADS)
 qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGeom bg, int bots_per_graph,
                      int max_agent, int win, int min_between, double r2thr, double corr,
                      double *__restrict__ drift, long long *__restrict__ last_closure,
-                     unsigned long long *__restrict__ counters, int raw_pose)
+                     unsigned long long *__restrict__ counters, int raw_pose, unsigned int *__restrict__ pile_flag)
 {
     // raw_pose: poses are used as given (PoseGraphSLAM.add_pose object API: the caller has already
     // applied its drift correction, dual_bot_mapper.py:855-857 precede :908)
@@ -429,6 +442,7 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
     __shared__ int s_ik[3];
     __shared__ int s_wk[2];                           // size of the window whose events are in n_*[parity]
     __shared__ long long s_nmisc;
+    __shared__ long long s_nlms;                      // DENSE: landmark-log entries whose stores are complete
 
     for (int t = tid; t < nb; t += CH_THREADS) {
         s_dx[0][t] = drift[2 * (bot0 + t)];
@@ -436,7 +450,7 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
         s_lastc[0][t] = last_closure[bot0 + t];
         s_acnt[t] = sb.agent_ev[bot0 + t];             // where the agent's next closure record goes
     }
-    if (tid == 0) { s_nmisc = Gp->n_misc; s_ik[0] = 0; s_ik[1] = 0; s_ik[2] = 0; }
+    if (tid == 0) { s_nmisc = Gp->n_misc; s_nlms = Gp->n_lms; s_ik[0] = 0; s_ik[1] = 0; s_ik[2] = 0; }
     if (tid < 96) {
         const int h = tid >> 5, t = tid & 31;
         i_idx[h][t] = LL_MAX; i_x[h][t] = 0; i_y[h][t] = 0; i_type[h][t] = 0;
@@ -554,6 +568,7 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
         const QsGraphDev G = *Gp;
         long long n_lms = G.n_lms, n_misc = G.n_misc;
         unsigned int pool = G.nodes_used;
+        bool pile = false;
         CH_P3_DECL;
         for (;;) {
             const bool active = e < e1;
@@ -563,10 +578,11 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
             // phase still see that window in LDS, the next phase's only in the index), and the side list's new length shows
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (lane == 0 && s_nmisc != n_misc) s_nmisc = n_misc;
+            if (DENSE && lane == 0) s_nlms = n_lms;
             if (have_prev) {
                 const int r1 = CH_R1;
                 if (s_ik[r1] > 0)
-                    chain_insert_window(G, bg, i_idx[r1], i_x[r1], i_y[r1], i_type[r1], s_ik[r1], lane, n_lms, n_misc, pool);
+                    chain_insert_window(G, bg, i_idx[r1], i_x[r1], i_y[r1], i_type[r1], s_ik[r1], lane, n_lms, n_misc, pool, pile);
             }
             CH_PHASE_END(active, k);
         }
@@ -576,6 +592,7 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
             Gp->n_lms = n_lms;
             Gp->n_misc = n_misc;
             Gp->nodes_used = pool;
+            if (pile && pile_flag) *pile_flag = 1u;
         }
     } else if (wave >= 1 && wave <= CH_AGW && wave - 1 < nb) {
         // =================================== query waves ===================================
@@ -620,6 +637,8 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
             const int lsl = lane < 32 ? CH_R2 : CH_R1;                     // lanes 0..31: window V - 2, lanes 32..63: window V - 1 (node order)
             const long long li = i_idx[lsl][lane & 31]; const double lx = i_x[lsl][lane & 31], ly = i_y[lsl][lane & 31]; const int lt = i_type[lsl][lane & 31];
             const long long nm = s_nmisc;
+            const long long nl = DENSE ? s_nlms : 0;
+            const int dense_after = (int)((nl >> 9) > 8 ? ((nl >> 9) < 100000 ? (nl >> 9) : 100000) : 8);     // DENSE: node rounds before a query scans the log
             const ChWindow W = chain_window(n_idx[par], n_a[par], &s_wk[par], active, lane, n_type[par], n_px[par], n_py[par]);
             const double o_dx = ONE ? c_dx : rlf64(c_dx, 0), o_dy = ONE ? c_dy : rlf64(c_dy, 0);     // lane 0's agent: drift at window start
             const bool ownlane = W.v_inw && (ONE ? W.v_a : W.v_a % CH_AGW) + 1 == wave;
@@ -657,6 +676,8 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
 #if defined(QS_CHAIN_PROF) || defined(QS_CHAIN_PROF2)
                 const unsigned long long tq1 = __builtin_amdgcn_s_memtime();
 #endif
+                int rounds = 0;
+                bool dense = false;
                 for (bool first_scan = true;; first_scan = false) {
                     const bool anyn = __ballot(node != 0) != 0;
                     long long id = LL_MAX;
@@ -677,6 +698,7 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
                         }
                     }
                     if (!anyn) break;
+                    if (DENSE && rounds++ == dense_after) { dense = true; break; }
                     CH_STAT(st_iters);
                     const bool inlim = node != 0 && id <= limit;      // empty slots read as a huge index
                     bool newhit = false;
@@ -702,12 +724,33 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
                 const unsigned long long tq2 = __builtin_amdgcn_s_memtime();
 #endif
                 double wx = 0, wy = 0;
-                if (gbest != LL_MAX) {                                  // uniform
+                if (DENSE && dense) {
+                    // self.landmarks in insertion order (:294): the first entry of the query's type within the radius among
+                    // those old enough (:300); entries are in node order, so the scan ends at the first one that is too new
+                    gbest = LL_MAX;
+                    const QS_GLOBAL long long *const g_idx = (const QS_GLOBAL long long *)Gp->lm_idx;
+                    const QS_GLOBAL unsigned char *const g_type = (const QS_GLOBAL unsigned char *)Gp->lm_type;
+                    const QS_GLOBAL double *const g_x = (const QS_GLOBAL double *)Gp->lm_x, *const g_y = (const QS_GLOBAL double *)Gp->lm_y;
+                    for (long long c0 = 0; c0 < nl; c0 += 2 * QS_WAVE) {
+                        st_misc++;                                      // (counted with the side-list rounds: linear scans)
+                        const long long k0 = c0 + lane, k1 = c0 + QS_WAVE + lane;
+                        long long i0 = LL_MAX, i1 = LL_MAX; int t0 = 0, t1 = 0; double x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+                        if (k0 < nl) { i0 = g_idx[k0]; t0 = g_type[k0]; x0 = g_x[k0]; y0 = g_y[k0]; }
+                        if (k1 < nl) { i1 = g_idx[k1]; t1 = g_type[k1]; x1 = g_x[k1]; y1 = g_y[k1]; }
+                        const double ax = qx - x0, ay = qy - y0, cx2 = qx - x1, cy2 = qy - y1;
+                        const bool c0ok = i0 <= limit && t0 == qtype && ax * ax + ay * ay < r2thr;
+                        const bool c1ok = i1 <= limit && t1 == qtype && cx2 * cx2 + cy2 * cy2 < r2thr;
+                        const unsigned long long m0 = __ballot(c0ok), m1 = __ballot(c1ok);
+                        if (m0) { const int w = __ffsll((long long)m0) - 1; gbest = rl64(i0, w); wx = rlf64(x0, w); wy = rlf64(y0, w); break; }
+                        if (m1) { const int w = __ffsll((long long)m1) - 1; gbest = rl64(i1, w); wx = rlf64(x1, w); wy = rlf64(y1, w); break; }
+                        if (__ballot((k0 < nl && i0 > limit) || (k1 < nl && i1 > limit))) break;
+                    }
+                } else if (gbest != LL_MAX) {                           // uniform
                     const int w = __ffsll((long long)__ballot(best == gbest)) - 1;
                     wx = rlf64(bx, w); wy = rlf64(by, w);
                 }
                 // landmarks outside the directory: linear scan in insertion order (rare)
-                if (nm > 0) {
+                if (nm > 0 && !(DENSE && dense)) {                     // (the log scan covers the side list's landmarks too)
                     const unsigned int *const misc = Gp->misc;
                     const long long *const lm_idx = Gp->lm_idx;
                     const unsigned char *const lm_type = Gp->lm_type;
@@ -898,14 +941,13 @@ hipError_t qs_launch_slam(qs_ctx *c, size_t n, bool raw_pose)
     hipLaunchKernelGGL(qs_slam_index_kernel, dim3(sb.n_blocks), dim3(IDX_BLOCK), (size_t)IDX_WAVES * G * 2 * sizeof(unsigned int),
                        c->stream, n, c->b, sb, c->d_graphs, c->bots_per_graph, G);
     StageTimer t_chain(c, QS_STAGE_SLAM_CHAIN);
-    if (c->bots_per_graph <= CH_AGW)
-        hipLaunchKernelGGL(qs_slam_chain_kernel<true>, dim3(G), dim3(CH_THREADS), 0, c->stream, c->d_graphs, sb, c->bg,
-                           c->bots_per_graph, c->cfg.max_agent, c->win, c->cfg.min_poses_between, c->r2_threshold,
-                           c->cfg.closure_correction, c->d_drift, c->d_last_closure, c->d_counters, raw_pose ? 1 : 0);
-    else
-        hipLaunchKernelGGL(qs_slam_chain_kernel<false>, dim3(G), dim3(CH_THREADS), 0, c->stream, c->d_graphs, sb, c->bg,
-                           c->bots_per_graph, c->cfg.max_agent, c->win, c->cfg.min_poses_between, c->r2_threshold,
-                           c->cfg.closure_correction, c->d_drift, c->d_last_closure, c->d_counters, raw_pose ? 1 : 0);
+#define CH_LAUNCH(ONE_, DENSE_) hipLaunchKernelGGL((qs_slam_chain_kernel<ONE_, DENSE_>), dim3(G), dim3(CH_THREADS), 0, c->stream, c->d_graphs, sb, c->bg, \
+                           c->bots_per_graph, c->cfg.max_agent, c->win, c->cfg.min_poses_between, c->r2_threshold,                          \
+                           c->cfg.closure_correction, c->d_drift, c->d_last_closure, c->d_counters, raw_pose ? 1 : 0, c->d_flags + 1)
+    const bool one = c->bots_per_graph <= CH_AGW;
+    if (c->pile_mode) { if (one) CH_LAUNCH(true, true); else CH_LAUNCH(false, true); }
+    else { if (one) CH_LAUNCH(true, false); else CH_LAUNCH(false, false); }
+#undef CH_LAUNCH
     t_chain.stop();
     if (raw_pose) return hipGetLastError();
     hipLaunchKernelGGL(qs_slam_pose_kernel, dim3((unsigned int)((n + 255) / 256)), dim3(256), 0, c->stream, n, c->b, sb);

@@ -1188,3 +1188,37 @@ def pkg_replay_adversarial(pkg, n, seed):
     import importlib
     replay = importlib.import_module(pkg.__name__ + ".replay")
     return replay.adversarial_stream(n, seed=seed, lo=-4.0, hi=4.0)
+
+
+def test_landmark_pile_dense_fallback(pkg):
+    """Row J1 (K4): the stream that defeats the bucket index -- a pile of landmarks in a neighbour bucket, out of reach of the
+    query point and older than the query's own first match, so every query walks the whole chain.  Once the insert wave has
+    seen a chain pass 64 pool nodes the library launches the chain kernel's DENSE variant, in which a runaway query scans the
+    insertion-ordered landmark log instead (the reference's own loop, a wave wide).  Same closures, landmarks and drift as the
+    oracle -- whose scan IS the reference's -- before, while and after the variant changes."""
+    P = pkg.protocol
+    L, NQ = 6000, 900
+    px, py, qx, qy = 0.05, 0.05, 0.75, 0.35                        # |PQ| = 0.76 m: neighbouring 0.6 m buckets, out of the 0.6 m radius
+    def pk(agent, x, y, n, lm=5):
+        return P.pack_packets(np.full(n, agent), np.full(n, x), np.full(n, y), np.zeros(n), np.zeros(n, dtype=int), np.zeros(n, dtype=int),
+                              np.full((n, 4), 0.3), np.full(n, lm))
+    rng = np.random.default_rng(2)
+    tail = np.concatenate([pk(1, px, py, 40), pk(2, qx, qy, 40), pk(2, qx + 0.3, qy - 0.2, 60), pk(1, px + 0.2, py + 0.1, 60)])
+    rng.shuffle(tail, axis=0)
+    stream = np.concatenate([pk(1, px, py, L), pk(2, qx, qy, NQ), tail])
+    o = orc.OracleMapper(512, 0.05, -12.8, -12.8, 0.0)
+    o.feed_stream(stream)
+    with pkg.QuasarMapper(512, 0.05, -12.8, -12.8) as m:
+        for lo, hi in ((0, 2500), (2500, L), (L, L + 300), (L + 300, len(stream))):      # the pile forms in the first batches
+            m.ingest_array(stream[lo:hi])
+        assert m.counters()["slam_misc_iters"] > 0                  # linear (log) scans happened: the DENSE variant ran
+        idx, corr = m.closures(0); oi, oc = o.closures(0)
+        assert len(oi) > 200 and (idx == oi).all() and np.abs(corr - oc).max() < FLOAT_TOL
+        xy, ti = m.landmarks(0); oxy, oti = o.landmarks(0)
+        assert (ti == oti).all() and np.abs(xy - oxy).max() < FLOAT_TOL
+        for b in (1, 2):
+            assert np.abs(m.drift(b) - o.drift(b)).max() < FLOAT_TOL
+        assert (m.grid_i8() == o.grid).all()
+        m.reset()                                                   # a new session starts with the plain variant again
+        m.ingest_array(stream[:200])
+        assert m.counters()["slam_misc_iters"] == 0
