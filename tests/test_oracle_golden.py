@@ -179,3 +179,25 @@ def test_frontiers_vs_reference(name):
     assert (st[:, 3:5] == fr[name + "_sums"]).all()
     cents = orc.cluster_centroids_world(st, res, ox, oy)
     assert (cents == fr[name + "_centroids"]).all()          # bit-exact: same integer sums, same fp64 ops
+
+
+@pytest.mark.parametrize("name", ["session_200", "session_sep_512", "laps5_512", "mixed_200", "adversarial_dense_200"])
+def test_pure_python_restatement_equals_reference_fixtures(name):
+    """oracle/pymapper.py -- the single-process Python baseline of bench.py and a second, independent statement
+    of the path -- against the fixtures the reference produced, and against oracle.c."""
+    import hashlib
+    from oracle.pymapper import PyMapper
+    g = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+    size, res, ox, oy, sep = g["cfg"]
+    pm = PyMapper(int(size), res, ox, oy, sep)
+    pm.feed_stream(g["datagrams"], g["lengths"])
+    assert hashlib.sha256(pm.grid.tobytes()).digest() == g["grid_sha256"].tobytes()
+    assert pm.accepted == int(g["accepted"].sum()) and pm.n_nodes == int(g["n_nodes"][0])
+    ci = np.array([(a, b) for a, b, _, _ in pm.closures], dtype=np.int64).reshape(-1, 2)
+    cc = np.array([(c, d) for _, _, c, d in pm.closures]).reshape(-1, 2)
+    assert (ci == g["closures_idx"]).all() and (len(cc) == 0 or np.abs(cc - g["closures_corr"]).max() < 1e-12)
+    o = orc.OracleMapper(int(size), res, ox, oy, sep)
+    o.feed_stream(g["datagrams"], g["lengths"])
+    assert (pm.grid == o.grid).all()
+    for b in (1, 2):
+        assert np.abs(np.array(pm.drift[b]) - o.drift(b)).max() == 0.0
