@@ -73,6 +73,9 @@ def parse(argv=None):
     ap.add_argument("--cpu-sample", type=int, default=0,
                     help="packets of the same stream timed on the CPU (0: one whole step; the reference's closure\n"
                          "search is O(landmarks) per landmark packet, so the rate depends on the length)")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="every rank uses cuda:0 (with --backend gloo): rehearses the N > 1 code path on a one-GPU box; "
+                         "the numbers mean nothing")
     ap.add_argument("--spawn-selftest", action="store_true",
                     help="no GPU: the ranks only rendezvous (backend as given), all-reduce one number and rank 0 prints "
                          "{n_gpus: world}; used by the CPU test of the launcher")
@@ -349,7 +352,7 @@ def selftest_rank(args):
 def run_rank(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.rehearse_on_one_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU", file=sys.stderr)
         return 2

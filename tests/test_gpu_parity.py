@@ -1222,3 +1222,23 @@ def test_landmark_pile_dense_fallback(pkg):
         m.reset()                                                   # a new session starts with the plain variant again
         m.ingest_array(stream[:200])
         assert m.counters()["slam_misc_iters"] == 0
+
+
+@pytest.mark.parametrize("extra", [[], ["--fuse", "direct"], ["--slam-mode", "replicated", "--bots", "31"]], ids=["per_shard", "direct_fuse", "replicated"])
+def test_bench_two_ranks_rehearsed_on_one_gpu(extra):
+    """The N > 1 path of bench.py end to end with the REAL HIP path on every rank: `python bench.py --gpus 2` starts its two
+    ranks itself; here both use cuda:0 and gloo carries the collectives (a one-GPU box has no second device for RCCL).  Each
+    rank ingests its own 64 bots (own tiles, global arrival indices), the grids are fused, and the bench's own parity check
+    -- fused stamps and fused counters of all ranks against the same fuse of the ranks' oracle grids, closures / landmarks /
+    drift per rank -- must hold.  The timings mean nothing here."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--rehearse-on-one-gpu",
+           "--batch", "65536", "--steps", "1", "--warmup", "1", "--no-micro"] + extra
+    out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["n_gpus"] == 2 and rec["parity_checked"] is True
+    assert rec["counters_per_step"]["closures"] > 100
