@@ -534,6 +534,16 @@ def run_rank(args):
             "roofline_raycast": raycast_entry,
             "parity_checked": parity, "parity_scope": parity_note,
         }
+        if world > 1:
+            # The N = 1 default is configs[1] (2 bots); this line is configs[3] (64 bots per GPU).  For a scaling figure on ONE
+            # workload, the same 64-bot workload at N = 1 -- replayed from the committed run, not measured now.
+            ref = os.path.join(ROOT, "profiles", "r02", f"bench_{wl}{'' if G == 4096 else '_' + str(G)}.json")
+            try:
+                r1 = json.load(open(ref))
+                out["same_workload_n1"] = {"value": r1["value"], "ms_per_step": r1["ms_per_step"],
+                                           "source": os.path.relpath(ref, ROOT) + " (python bench.py --workload " + wl + ", replayed)"}
+            except Exception:
+                out["same_workload_n1"] = None
         if micro is not None:
             out["roofline_streaming"] = micro
             out["copy_peak_measured_gbs"] = copy_gbs
