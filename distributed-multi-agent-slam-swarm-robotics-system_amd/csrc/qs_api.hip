@@ -214,7 +214,6 @@ extern "C" int qs_create(const qs_config *cfg, qs_ctx **out)
         if (nbd > 1024) nbd = 1024;
         unsigned int slab = 256;
         while ((double)slab < nbd * nbd) slab <<= 1;
-        if (const char *ev = getenv("QS_DIR_SLAB")) { const unsigned int v = (unsigned int)atoi(ev); if (v >= 256 && (v & (v - 1)) == 0) slab = v; }   // (experiment knob)
         c->bg = QsBucketGeom{cfg->ox, cfg->oy, cell, 1.0 / cell, slab - 1, 0};
         c->dir_entries = (size_t)QS_NTYPES * slab;
     }
