@@ -401,7 +401,7 @@ __device__ inline void chain_fetch(const QsSlamBatch &sb, unsigned int q0, unsig
 // lane arithmetic folds away.
 // DENSE: the variant for graphs that have grown a PILE -- a bucket chain of more than CH_PILE_NODES pool nodes.  A query whose
 // point is next to such a bucket but out of reach of its landmarks, and whose own first match is younger than the pile, walks
-// the whole chain: a dependent node read per 7 entries, the reference's O(L) scan only slower (tools/k4_adversarial.py: 5.8 ms
+// the whole chain: a dependent node read per 7 entries, the reference's O(L) scan only slower (tests/k4_adversarial.py: 5.8 ms
 // per query at 10^5 entries, 3.6 x the CPU's list scan).  In this variant a query that is still walking after
 // max(8, L / 512) node rounds scans the insertion-ordered landmark LOG instead, 128 entries per coalesced round -- the
 // reference's own loop (:294), a wave wide (0.46 ms per query on the same pile).  The insert wave raises a flag when a chain
