@@ -193,3 +193,13 @@ def test_bench_launcher_spawns_the_ranks_itself():
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     rec = json.loads(line)
     assert rec["n_gpus"] == 2 and rec["sum"] == 3.0
+
+
+def test_bench_refuses_a_gpus_flag_that_contradicts_the_launcher():
+    """Under torchrun (RANK / WORLD_SIZE set) bench.py is ONE rank; `--gpus` must then equal the world size (round 1 parsed
+    the flag and ignored it: `--gpus 8` printed n_gpus: 1)."""
+    import subprocess
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="3", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, text=True, timeout=120)
+    assert out.returncode == 2 and "WORLD_SIZE=3" in out.stderr and out.stdout.strip() == ""
