@@ -299,6 +299,52 @@ def micro_benches(pkg, torch, dev, m, grid):
     return out
 
 
+def secondary_64_bots(pkg, replay, torch, dev, side, args, G, counts):
+    """configs[2] in the same run (N = 1, default workload only): 64 bots in 32 pose graphs on this GPU, 5 timed steps, the last
+    one compared with the oracle -- so that the 64-bot figure is the driver's, not only the builder's."""
+    from oracle import oracle as orc
+    B, half = args.batch, G * 0.05 / 2
+    session, _ = replay.telemetry_csv_to_packets()
+    stream = replay.multi_bot_stream(session, 64, B)
+    d_stream = torch.from_numpy(stream).to(dev)
+    d_time = torch.arange(B, dtype=torch.float64, device=dev) * 0.25
+    m = pkg.QuasarMapper(G, 0.05, -half, -half, max_agent=64, bots_per_graph=2, enable_counts=counts, enable_ekf=bool(args.ekf),
+                         device=dev.index, raycast_mode=args.raycast_mode)
+    m.set_stream(side.cuda_stream)
+    steps, warm = 5, 2
+
+    def step():
+        m.reset()
+        m.ingest_device(d_stream.data_ptr(), B, 42, 0, d_time.data_ptr(), seq0=0)
+
+    for _ in range(warm):
+        step()
+    torch.cuda.synchronize()
+    m.stage_times(reset=True); m.timing_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    m.timing_enable(False)
+    st = {k: (v[0] / max(v[1], 1)) for k, v in m.stage_times(reset=True).items() if v[1]}
+    cnt = m.counters()
+    o = orc.OracleMapper(G, 0.05, -half, -half, 0.0, max_agent=64, bots_per_graph=2)
+    if args.ekf:
+        o.enable_ekf(0.0107)
+    t0 = time.perf_counter()
+    o.feed_stream(stream, None, np.arange(B) * 0.25)
+    cpu_s = time.perf_counter() - t0
+    bad = check_parity(m, o, m.n_graphs, 1, cnt, torch, None, None, dev)
+    for line in bad:
+        print(f"PARITY MISMATCH (64 bots): {line}", file=sys.stderr)
+    m.close()
+    return {"workload": f"configs[2]: 64 bots in 32 pose graphs, own room tiles, {G}x{G} grid, {B} packets/step, same stages",
+            "value": B * steps / el, "unit": "packets/s", "steps": steps, "warmup": warm, "ms_per_step": el / steps * 1e3,
+            "stages_ms_per_step": st, "parity_checked": not bad,
+            "cpu_baseline": {"value": B / cpu_s, "unit": "packets/s", "cores": 1, "kind": "port"}}
+
+
 def measured_copy_gbs(torch, dev):
     """Device-to-device copy bandwidth of this GPU in this run (bytes read + bytes written per second):
     the practical HBM ceiling next to the 8 TB/s spec peak."""
@@ -547,6 +593,10 @@ def run_rank(args):
         if micro is not None:
             out["roofline_streaming"] = micro
             out["copy_peak_measured_gbs"] = copy_gbs
+        if world == 1 and wl == "c1" and micro is not None and not args.no_cpu_baseline:
+            out["configs2_64_bots"] = secondary_64_bots(pkg, replay, torch, dev, side, args, G, counts)
+            if out["configs2_64_bots"]["parity_checked"] is False:
+                parity = False
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out))
