@@ -489,7 +489,12 @@ static int resolve_edge_rays(qs_ctx *c, uint64_t seq0)
 {
     unsigned int fl[2] = {0, 0};
     HIPCHK(c, hipMemcpyAsync(fl, c->d_flags, sizeof fl, hipMemcpyDeviceToHost, c->stream));
+    // (the same synchronisation brings the graphs' real landmark / closure counts: capacity planning starts from them, not from
+    // "every record so far was a landmark" -- ADVICE r1)
+    std::vector<QsGraphDev> cur((size_t)c->n_graphs);
+    HIPCHK(c, hipMemcpyAsync(cur.data(), c->d_graphs, cur.size() * sizeof(QsGraphDev), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int g = 0; g < c->n_graphs; g++) { c->lms_upper[g] = cur[g].n_lms; c->cls_upper[g] = cur[g].n_cls; }
     const unsigned int n_edge = fl[0];
     if (fl[1]) c->pile_mode = true;                      // a landmark pile has formed: the chain kernel's DENSE variant from now on
     c->edge_rays_total += n_edge;
