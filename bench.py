@@ -65,8 +65,10 @@ def parse(argv=None):
                          "per pose graph), 0 = all bots of the GPU in one graph")
     ap.add_argument("--slam-mode", default="per_shard", choices=["per_shard", "replicated"],
                     help="N > 1: pose graphs per shard, or ONE pose graph over all bots, its chain replicated on every rank")
-    ap.add_argument("--fuse", default="allreduce", choices=["allreduce", "direct"],
-                    help="N > 1 grid fuse: RCCL all-reduce, or point-to-point reduce-scatter + K3 fold + all-gather")
+    ap.add_argument("--fuse", default="sparse", choices=["sparse", "allreduce", "direct"],
+                    help="N > 1 grid fuse: sparse = only the 4 x 16-cell blocks a rank wrote since the last fuse travel (bitmap "
+                         "all-gather + point-to-point exchange of the packed blocks + fold); allreduce = RCCL's dense all-reduce of "
+                         "the whole map (the reference point); direct = dense point-to-point reduce-scatter + K3 fold + all-gather")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-micro", action="store_true", help="skip the K2 view / K3 fuse timings (N = 1 only anyway)")
@@ -101,11 +103,29 @@ def spawn_ranks(n, argv):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    # poll: a rank that dies (bad arguments, a HIP error, a parity mismatch) while its siblings sit in a collective must not
+    # leave the parent waiting for them -- first non-zero exit ends the others (terminate, then kill), and so does the limit
+    deadline = time.time() + float(os.environ.get("QS_BENCH_LIMIT_S", "3000"))
     rc = 0
-    for p in procs:
-        p.wait()
-        rc = rc or p.returncode
-    return rc
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [c for c in codes if c not in (None, 0)]
+        if bad or time.time() > deadline:
+            rc = bad[0] if bad else 124
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            t_kill = time.time() + 10
+            for p in procs:
+                try:
+                    p.wait(timeout=max(0.1, t_kill - time.time()))
+                except subprocess.TimeoutExpired:
+                    p.kill(); p.wait()
+            print(f"bench.py: rank exit codes {codes}: stopped the remaining ranks (exit {rc})", file=sys.stderr)
+            return rc
+        if all(c == 0 for c in codes):
+            return 0
+        time.sleep(0.2)
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -555,6 +575,21 @@ def run_rank(args):
         copy_gbs = measured_copy_gbs(torch, dev)
         micro = micro_benches(pkg, torch, dev, m, G)
     rc = 0
+    fuse_report = None
+    if world > 1:
+        # what ONE fuse moved (the last step's; every step is the same work): rank 0's figures and the maximum over the ranks
+        fs = dict(sm.fuse_stats)
+        dense = G * G * (4 + (8 if counts else 0))
+        mx = torch.tensor([fs.get("payload_bytes", 0), fs.get("sent_bytes", 0), fs.get("received_bytes", 0)], dtype=torch.int64, device=dev)
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        fuse_report = {"algorithm": args.fuse, "dense_map_bytes": dense,
+                       "payload_bytes_per_gpu": int(mx[0]), "payload_frac_of_dense_map": int(mx[0]) / dense,
+                       "sent_bytes_per_gpu": int(mx[1]), "received_bytes_per_gpu": int(mx[2]),
+                       "blocks_own": fs.get("blocks_own"), "blocks_all_ranks": fs.get("blocks_all"), "block_bytes": fs.get("block_bytes"),
+                       "note": ("payload = this rank's packed dirty blocks (4 x 16 cells: 64 stamps + 64 counter deltas), the bytes each "
+                                "of its N-1 links carries; sent = payload x (N-1) + the bitmap all-gather; max over the ranks"
+                                if args.fuse == "sparse" else
+                                "dense: the whole stamp grid (+ the counter snapshot); sent = 2 (N-1)/N x that on a ring")}
     if rank == 0:
         wl_name = {"c1": "configs[1]: 2-bot stream", "adv": "adversarial uniform-random stream (SURVEY 8(d) D2), 2 bots",
                    "c3": ("configs[3]" if world > 1 else "configs[2] shape") + f": {bots} bots/GPU in their own room tiles"}[wl]
@@ -574,6 +609,7 @@ def run_rank(args):
                        "pose_graphs_per_gpu": m.n_graphs, "slam_mode": ("replicated (one pose graph over all bots)" if replicated else
                                                                        "per_shard (pose graphs per shard)") if world > 1 else "single mapper",
                        "sharding": f"by agent, {world} x {bots} bots", "fuse": args.fuse if world > 1 else None},
+            "fuse": fuse_report,
             "stages_ms_per_step": st_ms,
             "counters_per_step": cnt,
             "roofline": roofline,

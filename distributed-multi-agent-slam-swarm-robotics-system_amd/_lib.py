@@ -101,6 +101,12 @@ SIGNATURES = {
     "qs_counts_source": (_i32, [_vp, _i32]),
     "qs_epoch_query": (_i32, [_vp, _u64, _sz, C.POINTER(_i32)]),
     "qs_mark_fused": (_i32, [_vp]),
+    "qs_dirty_tracking": (_i32, [_vp, _i32]),
+    "qs_dirty_blocks": (_i32, [_vp, C.POINTER(_sz), C.POINTER(_sz)]),
+    "qs_sparse_fuse_begin": (_i32, [_vp, _i32, _i32, C.POINTER(_vp), C.POINTER(_sz)]),
+    "qs_sparse_fuse_plan": (_i32, [_vp, _vp, _vp, C.POINTER(_vp), C.POINTER(_sz)]),
+    "qs_sparse_fuse_apply": (_i32, [_vp]),
+    "qs_fused_counts_buffer": (_i32, [_vp, C.POINTER(_vp), C.POINTER(_sz)]),
     "qs_grid_to_pcd": (_i32, [_vp, _vp, _i32, _i32, _f64, _f64, _f64, _vp, _sz, C.POINTER(_sz)]),
     "qs_rasterise": (_i32, [_vp, _vp, _sz, _f64, _vp, _vp, _vp]),
     "qs_icp": (_i32, [_vp, _vp, _sz, _vp, _sz, _f64, _i32, _f64, _f64, _vp, _vp, _vp, _vp]),

@@ -162,6 +162,9 @@ static int reset_state(qs_ctx *c)
     if (c->d_counts) HIPCHK(c, hipMemsetAsync(c->d_counts, 0, c->cells * sizeof(unsigned long long), c->stream));
     if (c->d_counts_fused) HIPCHK(c, hipMemsetAsync(c->d_counts_fused, 0, c->cells * sizeof(unsigned long long), c->stream));
     c->dirty_since_fuse = false;
+    if (c->d_dirty) HIPCHK(c, hipMemsetAsync(c->d_dirty, 0, c->dirty_words * sizeof(unsigned int), c->stream));
+    if (c->d_counts_sent) HIPCHK(c, hipMemsetAsync(c->d_counts_sent, 0, c->cells * sizeof(unsigned long long), c->stream));
+    c->sf_state = 0;
     HIPCHK(c, hipMemsetAsync(c->d_drift, 0, (size_t)nb * 2 * sizeof(double), c->stream));
     HIPCHK(c, qs_launch_fill_zone_identity(c));
     HIPCHK(c, hipMemsetAsync(c->d_counters, 0, QS_CNT_N * sizeof(unsigned long long), c->stream));
@@ -280,6 +283,7 @@ extern "C" int qs_destroy(qs_ctx *c)
     hipFree(c->d_last_closure); hipFree(c->d_zone); hipFree(c->d_counters); hipFree(c->d_graph_batch);
     hipFree(c->d_ekf); hipFree(c->d_ekf_prev); hipFree(c->d_ekf_ws); hipFree(c->d_graphs); hipFree(c->d_flags); hipFree(c->d_pkts); hipFree(c->d_lens);
     hipFree(c->d_time); hipFree(c->d_bin_ws); hipFree(c->d_frontier_ws);
+    hipFree(c->d_dirty); hipFree(c->d_counts_sent); hipFree(c->d_sf_bitmaps); hipFree(c->d_sf_lists); hipFree(c->d_sf_counts); hipFree(c->d_sf_payload);
     for (auto &p : c->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (auto e : c->ev_pool) hipEventDestroy(e);
     if (c->ekf_stream) { hipStreamSynchronize(c->ekf_stream); hipStreamDestroy(c->ekf_stream); }
@@ -402,10 +406,11 @@ static int ensure_epoch(qs_ctx *c, uint64_t seq0, size_t n_seq)
     if (n_seq > QS_EPOCH_LIMIT) return qs_fail(c, QS_E_RANGE, "batch too large for one stamp epoch (2^28 records)");
     if (epoch_would_rebase(c, seq0, n_seq)) {
         // A rebase collapses every written cell to ordinal 1.  In one mapper that keeps the order against all later
-        // writes; in a shard of a round-robin stream (seq_stride > 1) two ranks' unfused writes to one cell would tie
-        // afterwards, so the shards must have exchanged their stamps first (dist.ShardedMapper does: it asks
+        // writes; in a shard -- of a round-robin stream (seq_stride > 1) or of a replicated pose graph (shard_bots > 0:
+        // every rank sees every packet but casts only its own agents' rays) -- two ranks' unfused writes to one cell
+        // would tie afterwards, so the shards must have exchanged their stamps first (dist.ShardedMapper does: it asks
         // qs_epoch_query before every ingest).
-        if (c->cfg.seq_stride > 1 && c->dirty_since_fuse)
+        if ((c->cfg.seq_stride > 1 || c->cfg.shard_bots > 0) && c->dirty_since_fuse)
             return qs_fail(c, QS_E_STATE, "this batch crosses a stamp epoch: fuse the shards' grids (all-reduce + qs_mark_fused) first");
         HIPCHK(c, qs_launch_rebase(c));
         c->epoch_base = seq0 ? seq0 - 1 : 0;
@@ -984,6 +989,7 @@ extern "C" int qs_fuse_buffers_range(qs_ctx *c, const void *const *stamps_dev, c
     unsigned long long *dc = c->cfg.enable_counts ? (counts_into_fused ? c->d_counts_fused : c->d_counts) : nullptr;
     HIPCHK(c, qs_launch_fuse(c, (const unsigned int *const *)stamps_dev, (const unsigned long long *const *)counts_dev, n,
                              cell_offset, n_cells, dc));
+    if (!counts_into_fused) HIPCHK(c, qs_launch_sf_mark_range(c, cell_offset, n_cells));   // a local fold writes the grid too
     return QS_OK;
 }
 
@@ -1003,6 +1009,7 @@ extern "C" int qs_fused_counts(qs_ctx *c, void **fused_dev, size_t *bytes)
 {
     ARGCHK(c, c != nullptr && fused_dev != nullptr);
     if (!c->d_counts) return qs_fail(c, QS_E_INVAL, "qs_fused_counts: context created with enable_counts = 0");
+    if (c->d_dirty) return qs_fail(c, QS_E_STATE, "qs_fused_counts: dirty tracking is on -- the fused counters accumulate the sparse fuse's deltas");
     HIPCHK(c, hipSetDevice(c->device));
     const size_t nb = c->cells * sizeof(unsigned long long);
     if (!c->d_counts_fused) HIPCHK(c, hipMalloc((void **)&c->d_counts_fused, nb));
@@ -1012,11 +1019,129 @@ extern "C" int qs_fused_counts(qs_ctx *c, void **fused_dev, size_t *bytes)
     return QS_OK;
 }
 
+extern "C" int qs_fused_counts_buffer(qs_ctx *c, void **fused_dev, size_t *bytes)
+{
+    ARGCHK(c, c != nullptr && fused_dev != nullptr);
+    *fused_dev = c->d_counts_fused;
+    if (bytes) *bytes = c->d_counts_fused ? c->cells * sizeof(unsigned long long) : 0;
+    return QS_OK;
+}
+
 extern "C" int qs_counts_source(qs_ctx *c, int32_t fused)
 {
     ARGCHK(c, c != nullptr);
     if (fused && !c->d_counts_fused) return qs_fail(c, QS_E_INVAL, "qs_counts_source: no fused snapshot yet (qs_fused_counts)");
     c->counts_view_fused = fused != 0;
+    return QS_OK;
+}
+
+// ---- sparse fuse (sparse_fuse.hip; protocol in include/quasar_slam.h) --------------------------------------------------
+extern "C" int qs_dirty_tracking(qs_ctx *c, int32_t enable)
+{
+    ARGCHK(c, c != nullptr);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (!enable) {
+        hipFree(c->d_dirty); c->d_dirty = nullptr; c->geom.dirty = nullptr; c->geom.dirty_pitch = 0;
+        c->sf_state = 0;
+        return QS_OK;
+    }
+    if (c->d_dirty) return QS_OK;
+    if (c->dirty_since_fuse) return qs_fail(c, QS_E_STATE, "qs_dirty_tracking: the grid has unfused writes (enable it after qs_create / qs_reset / a fuse)");
+    c->blocks_x = (c->cfg.size + QS_DIRTY_BLOCK_W - 1) / QS_DIRTY_BLOCK_W;
+    c->blocks_y = (c->cfg.size + QS_DIRTY_BLOCK_H - 1) / QS_DIRTY_BLOCK_H;
+    const int pitch = (c->blocks_x + 31) / 32;
+    c->dirty_words = (size_t)c->blocks_y * pitch;
+    HIPCHK(c, hipMalloc((void **)&c->d_dirty, c->dirty_words * sizeof(unsigned int)));
+    HIPCHK(c, hipMemsetAsync(c->d_dirty, 0, c->dirty_words * sizeof(unsigned int), c->stream));
+    if (c->d_counts) {
+        const size_t nb = c->cells * sizeof(unsigned long long);
+        if (!c->d_counts_sent) HIPCHK(c, hipMalloc((void **)&c->d_counts_sent, nb));
+        // the fused counters accumulate deltas from here on: they start as "nothing sent", the local counters as all delta
+        HIPCHK(c, hipMemsetAsync(c->d_counts_sent, 0, nb, c->stream));
+        if (!c->d_counts_fused) HIPCHK(c, hipMalloc((void **)&c->d_counts_fused, nb));
+        HIPCHK(c, hipMemsetAsync(c->d_counts_fused, 0, nb, c->stream));
+        // counters written before tracking was switched on have no dirty bit: everything is marked once
+    }
+    c->geom.dirty = c->d_dirty; c->geom.dirty_pitch = pitch;
+    if (c->next_seq != 0) HIPCHK(c, qs_launch_sf_mark_range(c, 0, c->cells));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return QS_OK;
+}
+
+extern "C" int qs_dirty_blocks(qs_ctx *c, size_t *n_blocks, size_t *block_cells)
+{
+    ARGCHK(c, c != nullptr && n_blocks != nullptr);
+    if (!c->d_dirty) return qs_fail(c, QS_E_STATE, "qs_dirty_blocks: dirty tracking is off (qs_dirty_tracking)");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = io_reserve(c, sizeof(unsigned long long));
+    if (rc != QS_OK) return rc;
+    unsigned long long v = 0;
+    HIPCHK(c, qs_launch_sf_popcount(c, (unsigned long long *)c->d_io_ws));
+    HIPCHK(c, hipMemcpyAsync(&v, c->d_io_ws, sizeof v, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *n_blocks = (size_t)v;
+    if (block_cells) *block_cells = (size_t)QS_DIRTY_BLOCK_W * QS_DIRTY_BLOCK_H;
+    return QS_OK;
+}
+
+extern "C" int qs_sparse_fuse_begin(qs_ctx *c, int32_t world, int32_t rank, void **bitmaps_dev, size_t *bitmap_bytes)
+{
+    ARGCHK(c, c != nullptr && bitmaps_dev != nullptr && bitmap_bytes != nullptr);
+    ARGCHK(c, world >= 1 && world <= QS_SPARSE_MAX_WORLD && rank >= 0 && rank < world);
+    if (!c->d_dirty) return qs_fail(c, QS_E_STATE, "qs_sparse_fuse_begin: dirty tracking is off (qs_dirty_tracking)");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (world != c->sf_world) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, dev_realloc(&c->d_sf_bitmaps, (size_t)world * c->dirty_words));
+        HIPCHK(c, dev_realloc(&c->d_sf_lists, (size_t)world * c->dirty_words * 32));
+        HIPCHK(c, dev_realloc(&c->d_sf_counts, (size_t)world));
+        c->sf_world = world;
+        c->sf_n.assign(world, 0); c->sf_off.assign((size_t)world + 1, 0);
+    }
+    c->sf_rank = rank;
+    const size_t nb = c->dirty_words * sizeof(unsigned int);
+    HIPCHK(c, hipMemcpyAsync(c->d_sf_bitmaps + (size_t)rank * c->dirty_words, c->d_dirty, nb, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_dirty, 0, nb, c->stream));
+    *bitmaps_dev = c->d_sf_bitmaps; *bitmap_bytes = nb;
+    c->sf_state = 1;
+    return QS_OK;
+}
+
+extern "C" int qs_sparse_fuse_plan(qs_ctx *c, uint32_t *n_blocks, size_t *offsets, void **payload_dev, size_t *block_bytes)
+{
+    ARGCHK(c, c != nullptr && n_blocks != nullptr && offsets != nullptr && payload_dev != nullptr);
+    if (c->sf_state != 1) return qs_fail(c, QS_E_STATE, "qs_sparse_fuse_plan: call qs_sparse_fuse_begin (and all-gather the bitmaps) first");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, qs_launch_sf_lists(c));
+    HIPCHK(c, hipMemcpyAsync(c->sf_n.data(), c->d_sf_counts, (size_t)c->sf_world * sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const size_t bb = qs_sf_block_bytes(c);
+    size_t run = 0;
+    for (int s = 0; s < c->sf_world; s++) { c->sf_off[s] = run; run += (size_t)c->sf_n[s] * bb; n_blocks[s] = c->sf_n[s]; offsets[s] = c->sf_off[s]; }
+    c->sf_off[c->sf_world] = run; offsets[c->sf_world] = run;
+    if (run > c->sf_payload_bytes) {
+        size_t cap = c->sf_payload_bytes ? c->sf_payload_bytes : ((size_t)1 << 20);
+        while (cap < run) cap *= 2;
+        HIPCHK(c, dev_realloc(&c->d_sf_payload, cap));
+        c->sf_payload_bytes = cap;
+    }
+    HIPCHK(c, qs_launch_sf_pack(c, c->sf_n[c->sf_rank], c->d_sf_payload + c->sf_off[c->sf_rank]));
+    *payload_dev = c->d_sf_payload;
+    if (block_bytes) *block_bytes = bb;
+    c->sf_state = 2;
+    return QS_OK;
+}
+
+extern "C" int qs_sparse_fuse_apply(qs_ctx *c)
+{
+    ARGCHK(c, c != nullptr);
+    if (c->sf_state != 2) return qs_fail(c, QS_E_STATE, "qs_sparse_fuse_apply: call qs_sparse_fuse_plan (and exchange the segments) first");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, qs_launch_sf_apply(c));
+    c->sf_state = 0;
+    c->dirty_since_fuse = false;
+    if (c->d_counts) c->counts_view_fused = true;
     return QS_OK;
 }
 

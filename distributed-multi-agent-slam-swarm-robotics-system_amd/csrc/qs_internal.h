@@ -85,7 +85,13 @@ struct QsGeom {
     double res, ox, oy;
     double min_dist, max_dist;
     double inv_res;          // 1.0 / res: screens world_to_grid quotients, never decides one (raycast_common.h)
+    unsigned int *dirty;     // sparse fuse (sparse_fuse.hip): one bit per QS_DIRTY_BLOCK_H x QS_DIRTY_BLOCK_W block of cells written
+    int dirty_pitch;         //   since the last fuse, rows of dirty_pitch 32-bit words; nullptr = no tracking
 };
+
+// bit of the block that holds cell (x, y): word index and mask
+__host__ __device__ inline size_t qs_dirty_word(int x, int y, int pitch) { return (size_t)(y / QS_DIRTY_BLOCK_H) * pitch + (x / QS_DIRTY_BLOCK_W) / 32; }
+__host__ __device__ inline unsigned int qs_dirty_mask(int x) { return 1u << ((x / QS_DIRTY_BLOCK_W) & 31); }
 
 // ---- decoded batch (SoA, one slot per datagram of the batch) -----------------------------
 struct QsBatch {
@@ -124,6 +130,19 @@ struct qs_ctx {
     unsigned long long *d_counts_fused = nullptr; // [size][size]; snapshot of d_counts that a collective sums over the ranks
     bool counts_view_fused = false;              // qs_grid_counts / qs_grid_logodds read the fused snapshot
     bool dirty_since_fuse = false;               // cells written since the last qs_mark_fused (sharded streams: rebase guard)
+    // sparse fuse (sparse_fuse.hip)
+    unsigned int *d_dirty = nullptr;             // live bitmap [blocks_y][dirty_pitch]
+    size_t dirty_words = 0;
+    int blocks_x = 0, blocks_y = 0;
+    unsigned long long *d_counts_sent = nullptr; // [size][size]: this context's counters as of its last sparse fuse (deltas travel)
+    int sf_world = 0, sf_rank = 0;
+    unsigned int *d_sf_bitmaps = nullptr;        // [sf_world][dirty_words]: every rank's bitmap of the fuse in flight
+    unsigned int *d_sf_lists = nullptr;          // [sf_world][dirty_words * 32] block ids, ascending
+    unsigned int *d_sf_counts = nullptr;         // [sf_world] blocks per rank
+    unsigned char *d_sf_payload = nullptr; size_t sf_payload_bytes = 0;
+    std::vector<unsigned int> sf_n;              // host copy of d_sf_counts
+    std::vector<size_t> sf_off;                  // [sf_world + 1] byte offsets of the ranks' segments in the payload
+    int sf_state = 0;                            // 0 idle, 1 begun, 2 planned
     double *d_offset = nullptr;                  // [max_agent+1]
     double *d_drift = nullptr;                   // [max_agent+1][2]
     long long *d_last_closure = nullptr;         // [max_agent+1]
@@ -222,6 +241,13 @@ hipError_t qs_launch_grid_to_pcd(qs_ctx *c, const signed char *d_grid, int h, in
 hipError_t qs_launch_rasterise(qs_ctx *c, const double *d_xy, size_t n, double res, double minx,
                                double miny, int h, int w, signed char *d_grid);
 hipError_t qs_launch_bbox(qs_ctx *c, const double *d_xy, size_t n, unsigned long long *d_box4);
+// sparse_fuse.hip
+size_t qs_sf_block_bytes(const qs_ctx *c);
+hipError_t qs_launch_sf_mark_range(qs_ctx *c, size_t cell_off, size_t n_cells);
+hipError_t qs_launch_sf_lists(qs_ctx *c);
+hipError_t qs_launch_sf_pack(qs_ctx *c, unsigned int n_own, unsigned char *dst);
+hipError_t qs_launch_sf_apply(qs_ctx *c);
+hipError_t qs_launch_sf_popcount(qs_ctx *c, unsigned long long *d_out);
 // frontier.hip
 size_t qs_frontier_workspace_bytes(const qs_ctx *c);
 hipError_t qs_launch_frontier_label(qs_ctx *c, void *ws, bool with_clusters);

@@ -54,6 +54,7 @@ qs_raycast_direct_kernel(size_t n, QsBatch b, QsGeom geo, unsigned int *__restri
                 if ((!last || ray.valid) && x >= 0 && x < geo.size && y >= 0 && y < geo.size) {
                     const size_t c = (size_t)y * geo.size + x;
                     atomicMax(&stamps[c], key_free | (last ? 1u : 0u));
+                    qs_mark_dirty(geo, x, y);
                     if (COUNTS) atomicAdd(&counts[c], last ? (1ull << 32) : 1ull);
                     my_cells++;
                 }
@@ -118,6 +119,7 @@ qs_update_rays_kernel(size_t n, const double *__restrict__ rx, const double *__r
             if ((!last || ray.valid) && x >= 0 && x < geo.size && y >= 0 && y < geo.size) {
                 const size_t c = (size_t)y * geo.size + x;
                 atomicMax(&stamps[c], key_free | (last ? 1u : 0u));
+                qs_mark_dirty(geo, x, y);
                 if (COUNTS) atomicAdd(&counts[c], last ? (1ull << 32) : 1ull);
                 cells++;
             }
@@ -176,6 +178,7 @@ __global__ void qs_edge_cast_kernel(unsigned int n_edge, QsBatch b, const double
             if ((!last || ray.valid) && x >= 0 && x < geo.size && y >= 0 && y < geo.size) {
                 const size_t c = (size_t)y * geo.size + x;
                 atomicMax(&stamps[c], key_free | (last ? 1u : 0u));
+                qs_mark_dirty(geo, x, y);
                 if (COUNTS) atomicAdd(&counts[c], last ? (1ull << 32) : 1ull);
                 cells++;
             }

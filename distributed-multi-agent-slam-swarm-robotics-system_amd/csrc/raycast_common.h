@@ -32,6 +32,19 @@ __device__ inline bool qs_w2g_i32(double w, double o, const QsGeom &geo, int &ou
     return true;
 }
 
+// Sparse fuse (sparse_fuse.hip): a writer that goes straight to the grid marks the block of every cell it writes.  The bit
+// is read first: a ray's cells share a block four to sixteen at a time and the rays of a batch share rooms, so almost
+// every mark finds its bit set and costs one cached load (a stale 0 only repeats the atomic; bits are never cleared
+// while writers run).
+__device__ inline void qs_mark_dirty(const QsGeom &geo, int x, int y)
+{
+    if (geo.dirty) {
+        unsigned int *w = geo.dirty + qs_dirty_word(x, y, geo.dirty_pitch);
+        const unsigned int m = qs_dirty_mask(x);
+        if (!(__atomic_load_n(w, __ATOMIC_RELAXED) & m)) atomicOr(w, m);
+    }
+}
+
 struct QsRay { double ex, ey; bool valid; };
 
 // sin and cos of a ray heading: the device library's fp64 sincos (one argument reduction for both;

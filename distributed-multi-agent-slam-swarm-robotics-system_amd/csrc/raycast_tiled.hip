@@ -62,6 +62,8 @@ struct QtWorkspace {
     uint2 *recs;                 // [16n]       tile records: tile-relative end points, i8 x 4; stamp | observed-hit bit
     int tiles_x, n_tiles, nwg;
     size_t pk_per_wg;            // packets per workgroup (multiple of 64)
+    unsigned int *dirty;         // sparse fuse: bitmap of written 4 x 16-cell blocks (QsGeom::dirty), or nullptr
+    int dirty_pitch;
 };
 
 __device__ inline void qt_tile_range(int x0, int y0, int x1, int y1, int size, int &tx_lo, int &tx_hi,
@@ -151,6 +153,7 @@ qs_rays_kernel(size_t n, QsBatch b, QsGeom geo, QtWorkspace ws, unsigned int *__
                         if ((!last || valid) && x >= 0 && x < geo.size && y >= 0 && y < geo.size) {
                             const size_t c = (size_t)y * geo.size + x;
                             atomicMax(&stamps[c], key_free | (last ? 1u : 0u));
+                            qs_mark_dirty(geo, x, y);
                             if (COUNTS) atomicAdd(&counts[c], last ? (1ull << 32) : 1ull);
                             my_cells++;
                         }
@@ -311,6 +314,22 @@ __device__ inline void qt_merge_tile(unsigned int *s_stamp, unsigned int *s_cnt,
         unsigned int v[PER], g[PER];
         #pragma unroll
         for (int q = 0; q < PER; q++) v[q] = s_stamp[(my + q * ROWS) * QT_PITCH + mx];
+        if (ws.dirty) {
+            // sparse fuse: a wave holds one 64-cell tile row per q = four blocks side by side; every cell written in LDS
+            // has a stamp there, so the ballot of v != 0 is the row's written cells
+            #pragma unroll
+            for (int q = 0; q < PER; q++) {
+                const unsigned long long wm = __builtin_amdgcn_ballot_w64(v[q] != 0);
+                if (wm != 0 && (tid & (QS_WAVE - 1)) == 0) {
+                    const unsigned int nib = ((wm & 0xffffull) ? 1u : 0u) | ((wm & 0xffff0000ull) ? 2u : 0u) |
+                                             ((wm & 0xffff00000000ull) ? 4u : 0u) | ((wm >> 48) ? 8u : 0u);
+                    const int gy = ty0 + my + q * ROWS;
+                    unsigned int *w = ws.dirty + qs_dirty_word(tx0, gy, ws.dirty_pitch);
+                    const unsigned int m = nib << ((tx0 / QS_DIRTY_BLOCK_W) & 31);   // tx0 is a multiple of 64: the nibble stays in one word
+                    if ((__atomic_load_n(w, __ATOMIC_RELAXED) & m) != m) atomicOr(w, m);
+                }
+            }
+        }
         if (exclusive) {
             #pragma unroll
             for (int q = 0; q < PER; q++) g[q] = v[q] != 0 ? stamps[g0 + q * gstep] : 0xffffffffu;
@@ -510,6 +529,7 @@ hipError_t qs_launch_raycast_tiled(qs_ctx *c, size_t n, uint64_t seq0)
     ws.chunk_base = (unsigned int *)p; p += tbytes;
     ws.rays = (uint2 *)p; p += qt_align(4 * c->cap_batch * sizeof(uint2));
     ws.recs = (uint2 *)p;
+    ws.dirty = c->geom.dirty; ws.dirty_pitch = c->geom.dirty_pitch;
 
     const unsigned long long ord_base = 4ull * (seq0 - c->epoch_base);
     const unsigned long long ord_stride = 4ull * (unsigned long long)(c->cfg.seq_stride > 0 ? c->cfg.seq_stride : 1);

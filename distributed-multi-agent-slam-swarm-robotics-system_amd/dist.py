@@ -19,10 +19,15 @@ Two things differ between the ranks' streams and one mapper's, and each has a mo
 * the counters.  They are per-rank sums of the rank's own writes and are never all-reduced in place (a second
   all-reduce would add the peers' totals again): the collective sums a snapshot (qs_fused_counts).
 
-Fuse algorithms: "allreduce" = RCCL's all-reduce (ring/tree, its choice); "direct" = reduce-scatter by
-point-to-point exchange + local fold (the K3 kernel, qs_fuse_buffers_range) + all-gather: on a fully connected xGMI
-node every rank sends 1/N of the grid to each of its N-1 peers at once, so all seven links carry traffic in both phases
-(SURVEY.md section 5), where a ring is bound by one link.
+Fuse algorithms: "sparse" (default) = only the 4 x 16-cell blocks a rank has written since its last fuse travel: the
+ranks all-gather their dirty-block bitmaps (32 KiB each at 4096^2), every rank packs its blocks (64 stamps + 64 counter
+deltas, 768 B) and sends the packed segment to each peer point to point -- all xGMI links at once -- and folds what it
+receives (stamps MAX, counter deltas ADD); a shard by agent writes a few rooms, ~4 % of the map on configs[3], so ~8 MB
+leaves a GPU per link instead of 192 MiB going round a ring.  "allreduce" = RCCL's dense all-reduce of the whole map
+(ring/tree, its choice) -- the reference point; "direct" = dense reduce-scatter by point-to-point exchange + local fold
+(the K3 kernel, qs_fuse_buffers_range) + all-gather: on a fully connected xGMI node every rank sends 1/N of the grid to
+each of its N-1 peers at once, so all seven links carry traffic in both phases, where a ring is
+bound by one link.
 """
 import numpy as np
 
@@ -146,6 +151,140 @@ def allreduce_grids(mapper, device, group=None, counts=True, algo="allreduce", s
     return fused
 
 
+# ---- sparse fuse: dirty blocks only ------------------------------------------------------------------------------------
+class MapperSparseAdapter:
+    """The three device-side steps of a sparse fuse (include/quasar_slam.h: qs_sparse_fuse_*) as torch tensors aliasing the
+    context's buffers.  The CPU tests drive sparse_fuse() with a numpy adapter of the same shape."""
+
+    def __init__(self, mapper, device, same_stream=True):
+        """same_stream: the context runs on torch's current stream (collectives and kernels are then ordered by the stream);
+        otherwise every hand-over between the two streams is a host synchronisation."""
+        self.m, self.device, self.same_stream = mapper, device, same_stream
+
+    def _torch_sync(self):
+        import torch
+        if not self.same_stream and self.device.type == "cuda":
+            torch.cuda.current_stream().synchronize()
+
+    def begin(self, world, rank):
+        import torch
+        p, nb = self.m.sparse_fuse_begin(world, rank)
+        if not self.same_stream:
+            self.m.sync()
+        return torch.as_tensor(_DevArray(p, (world, nb // 4), "<i4"), device=self.device)
+
+    def plan(self, world):
+        import torch
+        self._torch_sync()                                      # the bitmaps have arrived
+        n, off, p, bb = self.m.sparse_fuse_plan(world)          # waits for the context's stream: the host needs the counts
+        if not self.same_stream:
+            self.m.sync()                                       # this rank's segment is packed
+        total = int(off[world])
+        buf = torch.as_tensor(_DevArray(p, (total,), "|u1"), device=self.device) if total else None
+        return n, off, buf, bb
+
+    def apply(self):
+        self._torch_sync()                                      # the peers' segments have arrived
+        self.m.sparse_fuse_apply()
+
+
+def all_gather_rows(t, rank, group=None):
+    """t: [world, n]; row `rank` is this rank's: after the call every row holds its rank's."""
+    import torch
+    import torch.distributed as dist
+    W = t.shape[0]
+    if W == 1:
+        return
+    if t.is_cuda and dist.get_backend(group) == "nccl":
+        dist.all_gather_into_tensor(t.view(-1), t[rank], group=group)       # in place: input is slice `rank` of the output
+    else:
+        parts = [torch.empty_like(t[rank]) for _ in range(W)]
+        dist.all_gather(parts, t[rank].clone(), group=group)
+        for p in range(W):
+            if p != rank:
+                t[p].copy_(parts[p])
+
+
+def exchange_segments(buf, off, rank, world, group=None):
+    """buf: flat byte tensor holding one segment per rank at [off[p], off[p+1]); this rank's is filled.  Sends it to every
+    peer and receives every peer's into its place: N-1 sends + N-1 receives in one batch (RCCL runs them concurrently:
+    point to point over xGMI, one link per peer).  Empty segments are skipped on both sides (every rank knows all sizes)."""
+    import torch.distributed as dist
+    mine = buf[int(off[rank]):int(off[rank + 1])]
+    ops = []
+    for p in range(world):
+        if p == rank:
+            continue
+        gp = dist.get_global_rank(group, p) if group is not None else p
+        if mine.numel():
+            ops.append(dist.P2POp(dist.isend, mine, gp, group))
+        if off[p + 1] > off[p]:
+            ops.append(dist.P2POp(dist.irecv, buf[int(off[p]):int(off[p + 1])], gp, group))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+
+
+def sparse_fuse(adapter, rank, world, group=None, stats=None):
+    """One sparse fuse over the ranks of `group`.  stats (dict, optional) receives the bytes this rank moved."""
+    bm = adapter.begin(world, rank)
+    all_gather_rows(bm, rank, group)
+    n, off, buf, bb = adapter.plan(world)
+    if world > 1 and buf is not None:
+        exchange_segments(buf, off, rank, world, group)
+    adapter.apply()
+    if stats is not None:
+        own = int(off[rank + 1] - off[rank])
+        stats.update(block_bytes=int(bb), blocks_own=int(n[rank]), blocks_all=int(n.sum()),
+                     payload_bytes=own,                                   # this rank's packed blocks = what each of its links carries
+                     sent_bytes=own * (world - 1) + (world - 1) * bm.shape[1] * 4,
+                     received_bytes=int(off[world]) - own + (world - 1) * bm.shape[1] * 4,
+                     bitmap_bytes=int(bm.shape[1] * 4))
+    return n
+
+
+def sparse_fuse_local(mappers, device):
+    """The same protocol among N contexts of ONE process on one GPU (the contexts play the ranks; device-to-device copies
+    play the collectives): configs[2]'s on-GPU merge of per-bot-group mappers, and how the tests rehearse N = 8."""
+    import torch
+    W = len(mappers)
+    ads = [MapperSparseAdapter(m, device) for m in mappers]
+    for m in mappers:
+        m.sync()
+    bms = [a.begin(W, r) for r, a in enumerate(ads)]
+    for m in mappers:
+        m.sync()
+    for r in range(W):
+        for p in range(W):
+            if p != r:
+                bms[r][p].copy_(bms[p][p])
+    torch.cuda.synchronize()
+    plans = [a.plan(W) for a in ads]
+    for m in mappers:
+        m.sync()
+    for r in range(W):
+        n, off, buf, _ = plans[r]
+        for p in range(W):
+            if p != r and off[p + 1] > off[p]:
+                buf[int(off[p]):int(off[p + 1])].copy_(plans[p][2][int(off[p]):int(off[p + 1])])
+    torch.cuda.synchronize()
+    for a in ads:
+        a.apply()
+    for m in mappers:
+        m.sync()
+    return [pl[0] for pl in plans][0]
+
+
+def fused_counts_view(mapper, device):
+    """int32 [size, size, 2] aliasing the fused counters as they stand (after a sparse fuse: the sum over the ranks)."""
+    import torch
+    p, _ = mapper.fused_counts_buffer()
+    if not p:
+        return None
+    n = mapper.size
+    return torch.as_tensor(_DevArray(p, (n, n, 2), "<i4"), device=device)
+
+
 class ShardedMapper:
     """One rank of an N-way deployment of the central mapper (one process per GPU).
 
@@ -156,9 +295,12 @@ class ShardedMapper:
                  and every rank ingests the interleaved whole.
     """
 
-    def __init__(self, mapper, device, rank, world, group=None, mode="per_shard", fuse="allreduce", same_stream=True):
+    def __init__(self, mapper, device, rank, world, group=None, mode="per_shard", fuse="sparse", same_stream=True,
+                 track_single_rank=False):
         if mode not in ("per_shard", "replicated"):
             raise ValueError("mode must be per_shard or replicated")
+        if fuse not in ("sparse", "allreduce", "direct"):
+            raise ValueError("fuse must be sparse, allreduce or direct")
         if mode == "per_shard" and world > 1 and mapper.cfg.seq_stride != world:
             raise ValueError("per_shard mode: create the mapper with seq_stride = world size")
         if mode == "replicated" and (mapper.cfg.seq_stride not in (0, 1) or (world > 1 and mapper.cfg.shard_bots <= 0)):
@@ -166,10 +308,17 @@ class ShardedMapper:
         self.m, self.device, self.rank, self.world, self.group = mapper, device, rank, world, group
         self.mode, self.fuse_algo, self.same_stream = mode, fuse, same_stream
         self._gather = None
+        self.fuse_stats = {}
+        self._sparse = None
+        if fuse == "sparse" and (world > 1 or track_single_rank):
+            mapper.dirty_tracking(True)           # every writer of the grid marks the blocks it touches from here on
+            self._sparse = MapperSparseAdapter(mapper, device, same_stream)
 
     def ingest(self, d_pkts, d_time=None, seq_base=0):
         """d_pkts: uint8 [B, stride] device tensor (this rank's batch); d_time: float64 [B] or None;
-        seq_base: global arrival index of record 0 of rank 0's batch.  Asynchronous."""
+        seq_base: global arrival index of record 0 of rank 0's batch.  The work is enqueued on the context's stream; with
+        exact_trig (the default) the call ends with one stream synchronisation (the edge-ray count is read back), with
+        exact_trig = False it returns without waiting for the GPU."""
         import torch
         import torch.distributed as dist
         B, stride = d_pkts.shape
@@ -196,13 +345,26 @@ class ShardedMapper:
             self._keep = (full,)
         if not self.same_stream:
             torch.cuda.current_stream().synchronize()
+        if self.m.epoch_would_rebase(W * B, seq_base):
+            self.fuse(counts=False)              # replicated shards own different agents' rays: exchange before the rebase too
         self.m.ingest_device(full.data_ptr(), W * B, stride, 0, t_ptr, seq0=seq_base)
         return W * B
 
     def fuse(self, counts=True):
+        """Fuse the ranks' grids.  Returns the tensor aliasing the fused counters (or None).  The sparse fuse always
+        carries the counter deltas of the blocks it moves (`counts` only matters to the dense algorithms)."""
+        if self._sparse is not None:
+            if not self.same_stream:
+                self.m.sync()
+            sparse_fuse(self._sparse, self.rank, self.world, self.group, stats=self.fuse_stats)
+            return fused_counts_view(self.m, self.device) if self.m.cfg.enable_counts else None
         if self.world == 1:
             self.m.mark_fused()
             return None
+        cells = self.m.size * self.m.size
+        dense = cells * 4 + (cells * 8 if (counts and self.m.cfg.enable_counts) else 0)
+        self.fuse_stats.update(payload_bytes=dense, sent_bytes=int(2 * (self.world - 1) / self.world * dense),
+                               received_bytes=int(2 * (self.world - 1) / self.world * dense))
         return allreduce_grids(self.m, self.device, self.group, counts=counts, algo=self.fuse_algo,
                                sync=not self.same_stream)
 

@@ -284,6 +284,12 @@ class QuasarMapper:
         self._chk(self._L.qs_fused_counts(self._h, C.byref(p), C.byref(b)), "qs_fused_counts")
         return p.value, b.value
 
+    def fused_counts_buffer(self):
+        """(device address, bytes) of the fused counters as they stand (no snapshot); address 0 before the first fuse."""
+        p, b = C.c_void_p(), C.c_size_t()
+        self._chk(self._L.qs_fused_counts_buffer(self._h, C.byref(p), C.byref(b)), "qs_fused_counts_buffer")
+        return p.value or 0, b.value
+
     def counts_source(self, fused):
         self._chk(self._L.qs_counts_source(self._h, int(bool(fused))), "qs_counts_source")
 
@@ -293,7 +299,38 @@ class QuasarMapper:
         return bool(w.value)
 
     def mark_fused(self):
+        """Record that the shards have exchanged their stamps.  Whoever fuses into the device buffers from outside (a
+        collective on dist.grid_tensors) calls this afterwards: it also drops the look-alike's cached .grid."""
         self._chk(self._L.qs_mark_fused(self._h), "qs_mark_fused")
+        self._map_version += 1
+
+    # -- sparse fuse: only the blocks written since the last fuse travel (include/quasar_slam.h) -----------------------
+    def dirty_tracking(self, on=True):
+        self._chk(self._L.qs_dirty_tracking(self._h, int(bool(on))), "qs_dirty_tracking")
+
+    def dirty_blocks(self):
+        """(blocks marked since the last sparse fuse, cells per block)."""
+        n, cells = C.c_size_t(), C.c_size_t()
+        self._chk(self._L.qs_dirty_blocks(self._h, C.byref(n), C.byref(cells)), "qs_dirty_blocks")
+        return n.value, cells.value
+
+    def sparse_fuse_begin(self, world, rank):
+        """-> (device address of the [world][bitmap_bytes] bitmap array, bitmap_bytes); slot `rank` holds this rank's."""
+        p, b = C.c_void_p(), C.c_size_t()
+        self._chk(self._L.qs_sparse_fuse_begin(self._h, world, rank, C.byref(p), C.byref(b)), "qs_sparse_fuse_begin")
+        return p.value, b.value
+
+    def sparse_fuse_plan(self, world):
+        """-> (n_blocks uint32 [world], offsets [world + 1] bytes, payload device address, block_bytes)."""
+        n = np.zeros(world, dtype=np.uint32)
+        off = np.zeros(world + 1, dtype=np.uintp)
+        p, bb = C.c_void_p(), C.c_size_t()
+        self._chk(self._L.qs_sparse_fuse_plan(self._h, _ptr(n), _ptr(off), C.byref(p), C.byref(bb)), "qs_sparse_fuse_plan")
+        return n, off.astype(np.int64), p.value or 0, bb.value
+
+    def sparse_fuse_apply(self):
+        self._chk(self._L.qs_sparse_fuse_apply(self._h), "qs_sparse_fuse_apply")
+        self._map_version += 1
 
     def grid_to_pcd(self, grid, res, ox, oy):
         """MapMerger.grid_to_pcd (map_merger.py:64-85) -> float64 [n,2] (x, y)."""

@@ -174,6 +174,33 @@ int qs_counts_source(qs_ctx *ctx, int32_t fused);
  * exchange has happened; an ingest that needs a rebase with unfused writes fails with QS_E_STATE. */
 int qs_epoch_query(qs_ctx *ctx, uint64_t seq0, size_t n, int32_t *would_rebase);
 int qs_mark_fused(qs_ctx *ctx);
+/* ---- sparse fuse: only the blocks a shard has written since its last fuse travel -------------------------------------
+ * The shared grid of dual_bot_mapper.py:785 kept in N pieces, fused without moving the whole map: a shard by agent writes
+ * a few rooms, not the world.  With tracking on, every writer of the grid (tiled raster merge, direct rays, edge rays,
+ * qs_update_rays, qs_fuse*) sets one bit per QS_DIRTY_BLOCK_H x QS_DIRTY_BLOCK_W block of cells it touches.  A fuse is
+ *   qs_sparse_fuse_begin   own bitmap -> slot `rank` of a [world][bitmap_bytes] device array (live bitmap cleared);
+ *                          the caller all-gathers that array over the ranks (RCCL; the slots are equal-sized);
+ *   qs_sparse_fuse_plan    block lists of every rank (ascending block index), this rank's blocks packed -- 64 stamps and,
+ *                          with counters, 64 counter DELTAS since this rank's previous sparse fuse -- at offsets[rank] of
+ *                          one payload buffer; n_blocks / offsets (bytes, world + 1 entries) tell the caller what to send
+ *                          (its own segment, to every peer) and where to receive (peer p's segment at offsets[p]);
+ *   qs_sparse_fuse_apply   every received block folded in: stamps MAX into the grid, deltas ADDED to the fused counters
+ *                          (which qs_grid_counts / qs_grid_logodds then read); qs_mark_fused implied.
+ * Result = the dense fuse (MAX all-reduce of the stamps, SUM of the counters) bit for bit, as long as every rank's grid
+ * was equal after the previous fuse (true from qs_reset on).  In this mode the fused counters accumulate deltas: do not
+ * mix with qs_fused_counts (refused while tracking is on).  world <= QS_SPARSE_MAX_WORLD. */
+#define QS_DIRTY_BLOCK_W 16
+#define QS_DIRTY_BLOCK_H 4
+#define QS_SPARSE_MAX_WORLD 64
+int qs_dirty_tracking(qs_ctx *ctx, int32_t enable);
+/* diagnostic: number of blocks marked since the last sparse fuse (waits for the stream) */
+int qs_dirty_blocks(qs_ctx *ctx, size_t *n_blocks, size_t *block_cells);
+int qs_sparse_fuse_begin(qs_ctx *ctx, int32_t world, int32_t rank, void **bitmaps_dev, size_t *bitmap_bytes);
+int qs_sparse_fuse_plan(qs_ctx *ctx, uint32_t *n_blocks /* [world] */, size_t *offsets /* [world + 1] */,
+                        void **payload_dev, size_t *block_bytes);
+int qs_sparse_fuse_apply(qs_ctx *ctx);
+/* the fused counters as they stand (no snapshot is taken): the sum over the ranks after a fuse; NULL before the first one */
+int qs_fused_counts_buffer(qs_ctx *ctx, void **fused_dev, size_t *bytes);
 /* MapMerger.grid_to_pcd  server_nodes/map_merger.py:64-85: cells > 50 -> (col*res+ox,
  * row*res+oy) in row-major order.  grid: host int8 [h][w]; returns the count in *n_out. */
 int qs_grid_to_pcd(qs_ctx *ctx, const int8_t *grid, int32_t h, int32_t w, double res,

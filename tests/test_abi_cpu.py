@@ -89,3 +89,12 @@ def test_legacy_v0_bridge_formats():
     assert (agent, x, y, yaw) == (3, 1.0, -2.0, 0.5) and (rg == ranges).all()
     assert P.unpack_v0(raw[:-1]) is None and P.unpack_v0(b"XXXX" + raw[4:]) is None
     assert P.pack_cmd(0.25, -1.0) == struct.pack("<4sff", b"CMD1", 0.25, -1.0)
+
+
+def test_sparse_fuse_block_constants_match_the_cpu_stand_in():
+    """tests/test_dist_cpu.py drives dist.sparse_fuse with a numpy adapter that mirrors the kernels' block / payload layout."""
+    import test_dist_cpu as T
+    txt = open(os.path.join(ROOT, "include", "quasar_slam.h")).read()
+    w = int(re.search(r"#define QS_DIRTY_BLOCK_W (\d+)", txt).group(1))
+    h = int(re.search(r"#define QS_DIRTY_BLOCK_H (\d+)", txt).group(1))
+    assert (w, h) == (T.BW, T.BH) and w * h == 64          # one lane per cell of a block

@@ -203,3 +203,137 @@ def test_bench_refuses_a_gpus_flag_that_contradicts_the_launcher():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, stdout=subprocess.PIPE,
                          stderr=subprocess.PIPE, text=True, timeout=120)
     assert out.returncode == 2 and "WORLD_SIZE=3" in out.stderr and out.stdout.strip() == ""
+
+
+# ---- round 3: the sparse (dirty-block) fuse -- the protocol of dist.sparse_fuse with a numpy adapter in the kernels' place ----
+BW, BH = 16, 4        # QS_DIRTY_BLOCK_W / QS_DIRTY_BLOCK_H (checked against the header in test_abi_cpu.py)
+
+
+class NumpySparseAdapter:
+    """CPU stand-in for dist.MapperSparseAdapter with the SAME bitmap layout (rows of `pitch` words, one bit per 4 x 16 block)
+    and payload layout (64 stamps + 64 counter deltas per block, ascending block index) as csrc/sparse_fuse.hip.  State =
+    what a context holds: stamps (max of own writes and everything fused so far), own counters, counters as of the last
+    fuse, fused counters."""
+
+    def __init__(self, size):
+        self.size = size
+        self.bx, self.by = -(-size // BW), -(-size // BH)
+        self.pitch = -(-self.bx // 32)
+        self.stamps = np.zeros((size, size), np.int32)
+        self.counts = np.zeros((size, size, 2), np.int32)          # [..., 0] misses, [..., 1] hits (the device's lo32 / hi32)
+        self.sent = np.zeros_like(self.counts)
+        self.fused = np.zeros_like(self.counts)
+        self.dirty = np.zeros((self.by, self.pitch), np.uint32)
+
+    def write(self, new_stamps, new_counts):
+        """The oracle's state after a batch becomes the context's: blocks where a stamp or a counter changed are marked."""
+        ch = (np.maximum(self.stamps, new_stamps) != self.stamps) | (new_counts != self.counts).any(axis=-1)
+        self.stamps = np.maximum(self.stamps, new_stamps); self.counts = new_counts.copy()
+        pad = np.zeros((self.by * BH, self.bx * BW), bool); pad[:self.size, :self.size] = ch
+        blk = pad.reshape(self.by, BH, self.bx, BW).any(axis=(1, 3))
+        for y, x in zip(*np.nonzero(blk)):
+            self.dirty[y, x // 32] |= np.uint32(1 << (x % 32))
+
+    def _cells(self, bid):
+        y0, x0 = (bid // (self.pitch * 32)) * BH, (bid % (self.pitch * 32)) * BW
+        return slice(y0, y0 + BH), slice(x0, min(x0 + BW, self.size)), min(BW, self.size - x0)
+
+    def begin(self, world, rank):
+        self.world, self.rank = world, rank
+        self.bm = torch.zeros((world, self.by * self.pitch), dtype=torch.int32)
+        self.bm[rank] = torch.from_numpy(self.dirty.reshape(-1).view(np.int32).copy())
+        self.dirty[:] = 0
+        return self.bm
+
+    def plan(self, world):
+        bits = self.bm.numpy().view(np.uint32)
+        self.lists = [[w * 32 + b for w in np.nonzero(bits[s])[0] for b in range(32) if bits[s][w] >> b & 1] for s in range(world)]
+        n = np.array([len(l) for l in self.lists], np.uint32)
+        bb = 64 * 4 + 64 * 8
+        off = np.concatenate([[0], np.cumsum(n.astype(np.int64) * bb)])
+        buf = torch.zeros(int(off[-1]), dtype=torch.uint8)
+        seg = buf.numpy()
+        for k, bid in enumerate(self.lists[self.rank]):
+            ys, xs, w = self._cells(bid)
+            st = np.zeros((BH, BW), np.int32); st[:, :w] = self.stamps[ys, xs]
+            d = np.zeros((BH, BW, 2), np.int32); d[:, :w] = self.counts[ys, xs] - self.sent[ys, xs]
+            self.sent[ys, xs] = self.counts[ys, xs]
+            o = int(off[self.rank]) + k * bb
+            seg[o:o + 256] = st.reshape(-1).view(np.uint8)
+            seg[o + 256:o + 768] = d.reshape(-1).view(np.uint8)
+        self.off, self.buf, self.bb = off, buf, bb
+        return n, off, (buf if len(buf) else None), bb
+
+    def apply(self):
+        seg = self.buf.numpy()
+        for s in range(self.world):
+            for k, bid in enumerate(self.lists[s]):
+                ys, xs, w = self._cells(bid)
+                o = int(self.off[s]) + k * self.bb
+                st = seg[o:o + 256].view(np.int32).reshape(BH, BW)[:, :w]
+                d = seg[o + 256:o + 768].view(np.int32).reshape(BH, BW, 2)[:, :w]
+                if s != self.rank:
+                    self.stamps[ys, xs] = np.maximum(self.stamps[ys, xs], st)
+                self.fused[ys, xs] += d
+
+
+def _worker_sparse(rank, world, port, q, size, pitch_m):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import oracle as orc
+        distmod = importlib.import_module(PKG_NAME + ".dist")
+        replay = importlib.import_module(PKG_NAME + ".replay")
+        session, _ = replay.telemetry_csv_to_packets()
+        half = size * 0.05 / 2
+        geo = dict(pitch=pitch_m, tiles_per_row=2 * world, origin=(-half + 3.0, -1.0))
+        n = 900                                                    # records per rank, three batches
+        # rank r: bots 2r, 2r + 1 (agents 1, 2 on its own wire, one pose graph); record i of rank r is global record i*W + r
+        shards = [replay.multi_bot_stream(session, 2, n, tile0=2 * r, **geo) for r in range(world)]
+        mine = shards[rank]
+        inter = np.empty((n * world, 42), np.uint8)
+        for r in range(world):
+            g = shards[r].copy(); g[:, 4] += 2 * r                 # globally unique agent ids for the one reference mapper
+            inter[r::world] = g
+        m = orc.OracleMapper(size, 0.05, -half, -half, 0.0, max_agent=2)
+        m.set_sequence(rank, world)
+        ref = orc.OracleMapper(size, 0.05, -half, -half, 0.0, max_agent=2 * world, bots_per_graph=2)
+        ad = NumpySparseAdapter(size)
+        ok, stats, moved = True, {}, []
+        for k in range(3):
+            lo, hi = k * n // 3, (k + 1) * n // 3
+            m.feed_stream(mine[lo:hi]); ref.feed_stream(inter[lo * world:hi * world])
+            ad.write(m.stamps.astype(np.int64).astype(np.int32), np.stack([m.misses, m.hits], axis=-1))
+            distmod.sparse_fuse(ad, rank, world, stats=stats)
+            moved.append(stats["blocks_own"])
+            ok = ok and bool((ad.stamps.astype(np.uint32) == ref.stamps).all() and (ad.fused[..., 1] == ref.hits).all()
+                             and (ad.fused[..., 0] == ref.misses).all())
+            # an empty fuse right after: nothing travels, nothing changes
+            distmod.sparse_fuse(ad, rank, world, stats=stats)
+            ok = ok and stats["blocks_all"] == 0 and bool((ad.fused[..., 1] == ref.hits).all())
+        dense = size * size * 12
+        q.put((rank, ok, moved, stats.get("bitmap_bytes"), dense))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,size,pitch_m", [(2, 704, 8.0), (3, 520, 1.5), (4, 1024, 6.0)], ids=["2_apart", "3_overlapping_ragged_edge", "4_apart"])
+def test_sparse_fuse_protocol_equals_single_mapper(world, size, pitch_m):
+    """dist.sparse_fuse over gloo: bitmaps all-gathered, every rank's packed dirty blocks sent to every peer point to
+    point, folded in.  After every batch the stamps and the fused counters of EVERY rank equal one mapper fed the
+    interleaved stream -- rooms apart (disjoint blocks), rooms on top of each other (the same blocks from three ranks, a grid
+    whose width is not a multiple of the block width) -- and later fuses move only what the new batch touched."""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_sparse, args=(r, world, port, q, size, pitch_m)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok, moved, bitmap_bytes, dense in res:
+        assert ok, f"rank {rank}: sparse-fused grid differs from the single mapper"
+        assert moved[0] > 0 and moved[0] * 768 < 0.35 * dense, moved          # a room, not the map
