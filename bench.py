@@ -10,10 +10,11 @@ Inputs are resident in HBM before the timed region.
 
 Workloads (--workload; "auto" picks by N):
   c1   BASELINE.json configs[1] (N = 1 default): the 2-bot generate_fake_dual_session.py session
-       (tests/golden/session_telemetry.csv, produced by the reference generator) cycled to B packets,
+       (the package's data/session_telemetry.csv, produced by the reference generator) cycled to B packets,
        4096^2 grid, res 0.05, origin -102.4, one pose graph (the reference's mapper).
   c3   configs[3] (N > 1 default; N = 1: configs[2]'s shape): 64 bots per GPU, bot i of rank r in room tile
-       r*64 + i of the 25 x 25 lattice (8 m pitch), one pose graph per 2 bots (the reference's deployment unit),
+       r*64 + i of the 25 x 25 lattice (8 m pitch), each replaying its own run of the reference generator (seed
+       42 + lane, data/multibot_sessions.npz), one pose graph per 2 bots (the reference's deployment unit),
        stamps carry the GLOBAL arrival index (seq = i*N + rank), one grid fuse per step (MAX on stamps, SUM on a
        snapshot of the counters).  Weak scaling: every GPU ingests B packets per step.
   adv  SURVEY.md 8(d) D2's adversarial stream: uniform-random poses / yaw / distances (seed 1234 + rank), 2 bots --
@@ -159,7 +160,8 @@ def make_stream(pkg, replay, wl, bots, B, grid, rank, world, replicated):
         if replicated:
             rec["agent"] = rec["agent"] + rank * bots
         return stream
-    return replay.multi_bot_stream(session, bots, B, tile0=rank * bots, agent0=(rank * bots + 1) if replicated else 1)
+    # every bot replays its own generator run (seed 42 + lane; replay.multibot_lanes): SURVEY.md 8(d) D2
+    return replay.multi_bot_stream(None, bots, B, tile0=rank * bots, agent0=(rank * bots + 1) if replicated else 1)
 
 
 def oracle_for(orc, grid, bots, bpg, ekf, wl):
@@ -319,19 +321,20 @@ def micro_benches(pkg, torch, dev, m, grid):
     return out
 
 
-def secondary_64_bots(pkg, replay, torch, dev, side, args, G, counts):
-    """configs[2] in the same run (N = 1, default workload only): 64 bots in 32 pose graphs on this GPU, 5 timed steps, the last
-    one compared with the oracle -- so that the 64-bot figure is the driver's, not only the builder's."""
+def secondary_64_bots(pkg, replay, torch, dev, side, args, G, counts, bpg=2, steps=5, warm=2):
+    """configs[2] in the same run (N = 1, default workload only): 64 bots on this GPU, every bot its own generator run, `steps`
+    timed steps, the last one compared with the oracle -- so that the 64-bot figures are the driver's, not only the builder's.
+    bpg = 2: 32 pose graphs (one per bot pair, the reference's deployment unit: one mapper process per two bots);
+    bpg = 0: ONE PoseGraphSLAM over all 64 bots, as the reference's class is written (node indices count every bot's poses,
+    dual_bot_mapper.py:267-275; cross-bot matches, :294-309) -- one chain workgroup, its 13 owner waves share the 64 agents."""
     from oracle import oracle as orc
     B, half = args.batch, G * 0.05 / 2
-    session, _ = replay.telemetry_csv_to_packets()
-    stream = replay.multi_bot_stream(session, 64, B)
+    stream = replay.multi_bot_stream(None, 64, B)                 # bot i: the reference generator run with seed 42 + i
     d_stream = torch.from_numpy(stream).to(dev)
     d_time = torch.arange(B, dtype=torch.float64, device=dev) * 0.25
-    m = pkg.QuasarMapper(G, 0.05, -half, -half, max_agent=64, bots_per_graph=2, enable_counts=counts, enable_ekf=bool(args.ekf),
+    m = pkg.QuasarMapper(G, 0.05, -half, -half, max_agent=64, bots_per_graph=bpg, enable_counts=counts, enable_ekf=bool(args.ekf),
                          device=dev.index, raycast_mode=args.raycast_mode)
     m.set_stream(side.cuda_stream)
-    steps, warm = 5, 2
 
     def step():
         m.reset()
@@ -349,7 +352,7 @@ def secondary_64_bots(pkg, replay, torch, dev, side, args, G, counts):
     m.timing_enable(False)
     st = {k: (v[0] / max(v[1], 1)) for k, v in m.stage_times(reset=True).items() if v[1]}
     cnt = m.counters()
-    o = orc.OracleMapper(G, 0.05, -half, -half, 0.0, max_agent=64, bots_per_graph=2)
+    o = orc.OracleMapper(G, 0.05, -half, -half, 0.0, max_agent=64, bots_per_graph=bpg)
     if args.ekf:
         o.enable_ekf(0.0107)
     t0 = time.perf_counter()
@@ -357,12 +360,19 @@ def secondary_64_bots(pkg, replay, torch, dev, side, args, G, counts):
     cpu_s = time.perf_counter() - t0
     bad = check_parity(m, o, m.n_graphs, 1, cnt, torch, None, None, dev)
     for line in bad:
-        print(f"PARITY MISMATCH (64 bots): {line}", file=sys.stderr)
+        print(f"PARITY MISMATCH (64 bots, {m.n_graphs} pose graphs): {line}", file=sys.stderr)
+    n_graphs = m.n_graphs
     m.close()
-    return {"workload": f"configs[2]: 64 bots in 32 pose graphs, own room tiles, {G}x{G} grid, {B} packets/step, same stages",
+    win = max(cnt["slam_windows"], 1)
+    return {"workload": f"configs[2]: 64 bots (own generator runs, seeds 42..105) in {n_graphs} pose graph{'s' if n_graphs > 1 else ''}, own room "
+                        f"tiles, {G}x{G} grid, {B} packets/step, same stages",
+            "pose_graphs_per_gpu": n_graphs, "bots_per_graph": bpg or 64,
             "value": B * steps / el, "unit": "packets/s", "steps": steps, "warmup": warm, "ms_per_step": el / steps * 1e3,
-            "stages_ms_per_step": st, "parity_checked": not bad,
-            "cpu_baseline": {"value": B / cpu_s, "unit": "packets/s", "cores": 1, "kind": "port"}}
+            "stages_ms_per_step": st, "closures_per_step": cnt["closures"], "slam_windows_per_step": cnt["slam_windows"],
+            "chain_cycles_per_window": cnt["slam_cycles"] / win,
+            "parity_checked": not bad,
+            "cpu_baseline": {"value": B / cpu_s, "unit": "packets/s", "cores": 1, "kind": "port",
+                             "sample": f"one whole step, oracle/oracle.c, {cpu_s:.1f} s"}}
 
 
 def measured_copy_gbs(torch, dev):
@@ -630,8 +640,9 @@ def run_rank(args):
             out["roofline_streaming"] = micro
             out["copy_peak_measured_gbs"] = copy_gbs
         if world == 1 and wl == "c1" and micro is not None and not args.no_cpu_baseline:
-            out["configs2_64_bots"] = secondary_64_bots(pkg, replay, torch, dev, side, args, G, counts)
-            if out["configs2_64_bots"]["parity_checked"] is False:
+            out["configs2_64_bots"] = secondary_64_bots(pkg, replay, torch, dev, side, args, G, counts, bpg=2)
+            out["configs2_64_bots_one_graph"] = secondary_64_bots(pkg, replay, torch, dev, side, args, G, counts, bpg=0, steps=3, warm=1)
+            if out["configs2_64_bots"]["parity_checked"] is False or out["configs2_64_bots_one_graph"]["parity_checked"] is False:
                 parity = False
         if cpu is not None:
             out["cpu_baseline"] = cpu

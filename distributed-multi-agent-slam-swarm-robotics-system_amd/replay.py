@@ -14,8 +14,12 @@ import numpy as np
 
 from . import protocol as P
 
-SESSION_CSV = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
-                           "tests", "golden", "session_telemetry.csv")
+DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
+# the reference generator's seed-42 session (tests/golden/make_golden.py wrote it; byte-identical to the golden fixture)
+SESSION_CSV = os.path.join(DATA, "session_telemetry.csv")
+# 64 lanes, lane i = the bot-1 (even i) / bot-2 (odd i) packets of the reference generator run with seed 42 + i
+# (tests/golden/make_multibot_sessions.py, build container only)
+MULTIBOT_NPZ = os.path.join(DATA, "multibot_sessions.npz")
 
 
 def telemetry_csv_to_packets(path=SESSION_CSV):
@@ -39,20 +43,36 @@ def cycle_stream(pkts, n):
     return np.ascontiguousarray(np.tile(pkts, (reps, 1))[:n])
 
 
+def multibot_lanes(path=MULTIBOT_NPZ):
+    """The per-bot sessions of SURVEY.md 8(d) D2: list of 64 record arrays, lane i generated with seed 42 + i."""
+    z = np.load(path, allow_pickle=False)
+    rec = z["packets"].view(P.PACKET_DTYPE).reshape(-1)
+    st = z["lane_start"]
+    return [rec[st[i]:st[i + 1]] for i in range(len(st) - 1)]
+
+
 def multi_bot_stream(pkts, n_bots, n, pitch=8.0, tiles_per_row=25, origin=(-98.0, -98.0), lap_shift=37, tile0=0,
                      agent0=1):
     """configs C3/C4 (build-defined; the reference has no >2-bot generator): bot i (agent id
     agent0+i) lives in its own room tile (lattice position tile0+i: rank r of a sharded deployment passes
     tile0 = r*n_bots, so the 512 bots of configs[3] occupy 512 different tiles of the 25 x 25 lattice) on a
-    `pitch`-metre lattice and replays the session's bot-1 (even i) or bot-2 (odd i) packets, started
-    `lap_shift*(tile0+i)` packets into the lap; streams are interleaved round-robin, n packets in total."""
-    rec = pkts.view(P.PACKET_DTYPE).reshape(-1)
-    lanes = [rec[rec["agent"] == 1], rec[rec["agent"] == 2]]
+    `pitch`-metre lattice; streams are interleaved round-robin, n packets in total.
+    pkts = None: bot i replays ITS OWN session -- lane (tile0 + i) mod 64 of multibot_lanes(): the reference generator run
+    with seed 42 + lane, bot-1 waypoints for even lanes, bot-2 for odd ones, own sensor noise and odometry drift (beyond
+    64 bots the lanes repeat, in different tiles).  pkts = a 2-bot session: every bot replays that session's bot-1 (even i)
+    or bot-2 (odd i) packets (two noise realisations in all; rounds 1-2, kept for the tests that pin it).  Either way bot i
+    starts `lap_shift*(tile0+i)` packets into its lap."""
+    if pkts is None:
+        all_lanes = multibot_lanes()
+        lanes = None
+    else:
+        rec = pkts.view(P.PACKET_DTYPE).reshape(-1)
+        lanes = [rec[rec["agent"] == 1], rec[rec["agent"] == 2]]
     per_bot = -(-n // n_bots)
     out = np.zeros((per_bot, n_bots), dtype=P.PACKET_DTYPE)
     for i in range(n_bots):
-        src = lanes[i & 1]
         t = tile0 + i
+        src = lanes[i & 1] if lanes is not None else all_lanes[t % len(all_lanes)]
         idx = (np.arange(per_bot) + lap_shift * t) % len(src)
         r = src[idx].copy()
         tx = origin[0] + pitch * (t % tiles_per_row)

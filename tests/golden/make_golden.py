@@ -308,6 +308,11 @@ def main():
     assert telem == telem2, "generator is not deterministic"
     with open(os.path.join(HERE, "session_telemetry.csv"), "wb") as f:
         f.write(telem)
+    # the package reads its own copy (replay.SESSION_CSV): the product does not reach into tests/
+    pkg_data = os.path.join(os.path.dirname(os.path.dirname(HERE)), "distributed-multi-agent-slam-swarm-robotics-system_amd", "data")
+    os.makedirs(pkg_data, exist_ok=True)
+    with open(os.path.join(pkg_data, "session_telemetry.csv"), "wb") as f:
+        f.write(telem)
     pkts, times = telemetry_to_packets(mapper, telem)
     stream = b"".join(pkts)
     kat["session"] = {

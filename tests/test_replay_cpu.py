@@ -35,3 +35,30 @@ def test_synthetic_streams_shape_and_determinism():
     assert (replay.multi_bot_stream(pk, 64, 6400) == m).all()
     a = replay.adversarial_stream(1000)
     assert a.shape == (1000, 42) and (replay.adversarial_stream(1000) == a).all()
+
+
+def test_per_bot_sessions_fixture():
+    """SURVEY.md 8(d) D2 / VERDICT r2 item 7: 64 lanes, lane i = the reference generator run with seed 42 + i (bot-1 rows for
+    even i, bot-2 rows for odd i), written by tests/golden/make_multibot_sessions.py in the build container.  Lane 0 is the
+    bot-1 half of the committed seed-42 session; every lane has its own noise; the package's copy of the session CSV is the
+    golden one byte for byte (the product reads its own data directory, not tests/)."""
+    pkg = load_pkg()
+    replay = importlib.import_module(pkg.__name__ + ".replay")
+    P = pkg.protocol
+    assert open(replay.SESSION_CSV, "rb").read() == open(os.path.join(GOLDEN, "session_telemetry.csv"), "rb").read()
+    assert os.path.dirname(replay.SESSION_CSV).startswith(os.path.dirname(os.path.abspath(replay.__file__)))
+    lanes = replay.multibot_lanes()
+    assert len(lanes) == 64 and all(300 < len(l) < 400 for l in lanes)
+    pk, _ = replay.telemetry_csv_to_packets()
+    rec = pk.view(P.PACKET_DTYPE).reshape(-1)
+    assert lanes[0].tobytes() == rec[rec["agent"] == 1].tobytes()
+    assert all((l["agent"] == 1 + (i & 1)).all() for i, l in enumerate(lanes))
+    # own noise: no two even lanes report the same distances, yet all follow the same waypoints (poses within the room)
+    sig = {hashlib.sha256(l["front"].tobytes() + l["left"].tobytes()).hexdigest() for l in lanes}
+    assert len(sig) == 64
+    assert all(-1.5 < l["x"].min() and l["x"].max() < 6.5 and -3.0 < l["y"].min() and l["y"].max() < 3.0 for l in lanes)
+    m = replay.multi_bot_stream(None, 64, 6400, tile0=64)
+    r = m.view(P.PACKET_DTYPE).reshape(-1)
+    assert r["agent"].min() == 1 and r["agent"].max() == 64 and np.abs(r["x"]).max() < 102.4
+    assert (replay.multi_bot_stream(None, 64, 6400, tile0=64) == m).all()
+    assert not (replay.multi_bot_stream(None, 64, 6400, tile0=0) == m).all()
