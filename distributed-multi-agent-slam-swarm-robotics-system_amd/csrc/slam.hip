@@ -161,7 +161,8 @@ qs_slam_index_kernel(size_t n, QsBatch b, QsSlamBatch sb, const QsGraphDev *__re
 // fetch wave shares SIMD 2 with owner 2 -- the other way round costs 2 %)
 #define CH_INS (CH_WAVES - 1)       // the wave that moves a committed window into the HBM index
 #define CH_FETCH (CH_WAVES - 2)     // the wave that fetches the events
-#define CH_AGW (CH_WAVES - 3)       // query waves 1 .. CH_AGW: agent a belongs to wave 1 + a % CH_AGW
+#define CH_AGW (CH_WAVES - 3)       // query waves 1 .. CH_AGW: with at most CH_AGW agents in the graph (ONE) agent a belongs to wave 1 + a for
+                                    // good; with more, the fetch wave deals every window's agents to the waves (chain_fetch)
 
 // barrier that orders LDS traffic only (the hand-offs between the roles go through LDS; a full
 // __syncthreads would also wait for every outstanding global store to be acknowledged)
@@ -366,8 +367,15 @@ __device__ inline ChWindow chain_window(const long long *nidx, const int *na, co
     return w;
 }
 // fetch wave: 32 events from position q0 on, laid out as the window that starts there
+// DYN (graphs with more agents than owner waves): the fetch wave also deals the window's agents to the owner waves -- the r-th
+// distinct agent of the window (in order of its first event) goes to wave 1 + r mod n_ow -- so that a window's queries spread
+// over the owners whatever the agents' numbers are: nown[l] = the owner wave of event l, inwin[a] = the owner wave of agent a
+// while it has events in the window in this buffer (0 otherwise; the marks of the window that used the buffer before are
+// taken back first).
+template <bool DYN>
 __device__ inline void chain_fetch(const QsSlamBatch &sb, unsigned int q0, unsigned int e1, int lane, int win, long long *nidx, int *na,
-                                   int *ntype, double *npx, double *npy, int *wk)
+                                   int *ntype, double *npx, double *npy, int *wk, int *nown = nullptr, int *inwin = nullptr,
+                                   int n_ow = 1, bool clear_old = false)
 {
     const unsigned int q = q0 + lane;
     long long f_idx = LL_MAX; int f_a = 0, f_type = 0; double f_px = 0, f_py = 0;
@@ -376,6 +384,19 @@ __device__ inline void chain_fetch(const QsSlamBatch &sb, unsigned int q0, unsig
     const long long first = rl64(f_idx, 0);
     const bool inw = have && f_idx - first < win;
     const int k = __popcll(__ballot(inw));
+    if (DYN) {
+        int ow = 0, r = 0;
+        for (unsigned long long rem = __ballot(inw); rem; r = (r + 1 == n_ow) ? 0 : r + 1) {
+            const int ld = __ffsll((long long)rem) - 1;
+            const int aa = __builtin_amdgcn_readlane(f_a, ld);
+            const unsigned long long grp = __ballot(inw && f_a == aa);
+            if (inw && f_a == aa) ow = 1 + r;
+            rem &= ~grp;
+        }
+        if (clear_old && lane < 32) { const int oa = na[lane]; if (oa >= 0) inwin[oa] = 0; }
+        if (inw) inwin[f_a] = ow;                        // (after the line above in program order: LDS keeps a wave's stores in order)
+        if (lane < 32) nown[lane] = ow;
+    }
     if (lane < 32) { nidx[lane] = f_idx; na[lane] = inw ? f_a : -1; ntype[lane] = f_type; npx[lane] = f_px; npy[lane] = f_py; }
     if (lane == 0) *wk = k;
 }
@@ -441,6 +462,10 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
     __shared__ int i_type[3][32];
     __shared__ int s_ik[3];
     __shared__ int s_wk[2];                           // size of the window whose events are in n_*[parity]
+    // !ONE (more agents than owner waves): owner wave of every event / of every agent with events in the window (chain_fetch)
+    __shared__ int n_own[ONE ? 1 : 2][ONE ? 1 : 32];
+    __shared__ int s_inwin[ONE ? 1 : 2][ONE ? 1 : QS_MAX_AGENT + 1];
+    const int n_ow = min(CH_AGW, nb);               // owner waves in use
     __shared__ long long s_nmisc;
     __shared__ long long s_nlms;                      // DENSE: landmark-log entries whose stores are complete
 
@@ -451,6 +476,11 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
         s_acnt[t] = sb.agent_ev[bot0 + t];             // where the agent's next closure record goes
     }
     if (tid == 0) { s_nmisc = Gp->n_misc; s_nlms = Gp->n_lms; s_ik[0] = 0; s_ik[1] = 0; s_ik[2] = 0; }
+    if (!ONE) {
+        for (int t = tid; t < 2 * (QS_MAX_AGENT + 1); t += CH_THREADS) (&s_inwin[0][0])[t] = 0;
+        if (tid < 64) { (&n_own[0][0])[tid] = 0; (&n_a[0][0])[tid] = -1; }
+        __syncthreads();                             // (n_a is read back by the first fetches into each buffer)
+    }
     if (tid < 96) {
         const int h = tid >> 5, t = tid & 31;
         i_idx[h][t] = LL_MAX; i_x[h][t] = 0; i_y[h][t] = 0; i_type[h][t] = 0;
@@ -459,7 +489,10 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
 
     const unsigned int e0 = sb.ev_base[g], e1 = sb.ev_base[g + 1];
 
-    if (wave == CH_FETCH) chain_fetch(sb, e0, e1, lane, win, n_idx[0], n_a[0], n_type[0], n_px[0], n_py[0], &s_wk[0]);
+    if (wave == CH_FETCH) {
+        if (ONE) chain_fetch<false>(sb, e0, e1, lane, win, n_idx[0], n_a[0], n_type[0], n_px[0], n_py[0], &s_wk[0]);
+        else chain_fetch<true>(sb, e0, e1, lane, win, n_idx[0], n_a[0], n_type[0], n_px[0], n_py[0], &s_wk[0], n_own[0], s_inwin[0], n_ow, true);
+    }
     __syncthreads();
 
     unsigned int e = e0;
@@ -559,7 +592,17 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
             const bool active = e < e1;
             if (!active && !have_prev) break;
             const int k = active ? s_wk[par] : 0;
-            if (active) chain_fetch(sb, e + k, e1, lane, win, n_idx[par ^ 1], n_a[par ^ 1], n_type[par ^ 1], n_px[par ^ 1], n_py[par ^ 1], &s_wk[par ^ 1]);
+            if (!ONE && active) {
+                // the states of the agents WITHOUT events in window V go over to the next window unchanged (those with events are
+                // written by the owner wave they were dealt to): one writer per word
+                for (int a = lane; a < nb; a += QS_WAVE)
+                    if (s_inwin[par][a] == 0) { s_dx[par ^ 1][a] = s_dx[par][a]; s_dy[par ^ 1][a] = s_dy[par][a]; s_lastc[par ^ 1][a] = s_lastc[par][a]; }
+            }
+            if (active) {
+                if (ONE) chain_fetch<false>(sb, e + k, e1, lane, win, n_idx[par ^ 1], n_a[par ^ 1], n_type[par ^ 1], n_px[par ^ 1], n_py[par ^ 1], &s_wk[par ^ 1]);
+                else chain_fetch<true>(sb, e + k, e1, lane, win, n_idx[par ^ 1], n_a[par ^ 1], n_type[par ^ 1], n_px[par ^ 1], n_py[par ^ 1], &s_wk[par ^ 1],
+                                       n_own[par ^ 1], s_inwin[par ^ 1], n_ow, true);
+            }
             CH_PHASE_END(active, k);
         }
         CH_P3_REPORT(QS_CNT_SLAM_CYC_B);
@@ -594,16 +637,21 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
             Gp->nodes_used = pool;
             if (pile && pile_flag) *pile_flag = 1u;
         }
-    } else if (wave >= 1 && wave <= CH_AGW && wave - 1 < nb) {
+    } else if (wave >= 1 && wave <= n_ow) {
         // =================================== query waves ===================================
-        // lane j keeps drift and last closure of agent (wave - 1) + CH_AGW * j -- the authoritative copy;
-        // nothing else writes an agent's state
+        // ONE: the wave owns agent wave - 1 for good; its drift and last closure live in the wave's registers (every lane) -- the
+        // authoritative copy, nothing else writes them.
+        // !ONE: the agents' states live in LDS, double-buffered by window parity; an agent with events in the window belongs to
+        // the owner wave the fetch wave dealt it to (chain_fetch), which reads its state at window start and writes its state
+        // after the window; the states of the agents WITHOUT events in the window are carried over by the fetch wave.  Every
+        // state word has exactly one writer per phase, and its readers come a barrier later.  An owner without an event in the
+        // window goes straight to the barrier: with 64 agents in one graph the workgroup is bound by instruction issue on its
+        // four SIMDs (16 waves), not by any one wave's latency.
         __builtin_amdgcn_s_setprio(3);             // the decisions are the critical path: ahead of the helper waves on a shared SIMD
-        const int own = (wave - 1) + CH_AGW * lane;
+        const int own = (wave - 1) + n_ow * lane;  // (!ONE: the agents whose final state this wave writes back at the end)
         double c_dx = 0, c_dy = 0;
         long long c_last = 0;
         if (ONE) { c_dx = s_dx[0][wave - 1]; c_dy = s_dy[0][wave - 1]; c_last = s_lastc[0][wave - 1]; }     // one agent: every lane holds its state
-        else if (own < nb) { c_dx = s_dx[0][own]; c_dy = s_dy[0][own]; c_last = s_lastc[0][own]; }
         const QsNodeG g_nodes = (QsNodeG)Gp->nodes;
         const QsU32G g_next = (QsU32G)Gp->nd_next;
         // lane = (bucket of the 3x3 neighbourhood, entry of that bucket's current 7-entry node): a node
@@ -632,6 +680,15 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
             const unsigned long long p2_t0 = __builtin_amdgcn_s_memtime();
             p2_bar += p2_t0 - p2_t4;
 #endif
+            int ev_own = 0;
+            if (!ONE) {
+                ev_own = (active && lane < 32) ? n_own[par][lane] : 0;
+                if (__ballot(ev_own == wave) == 0) {               // none of the window's agents is this wave's
+                    const int k0 = active ? s_wk[par] : 0;
+                    CH_PHASE_END(active, k0);
+                    continue;
+                }
+            }
             // window V - 1 is not in the index yet: its landmarks (final poses) are in LDS, in node order.  Read in
             // the same LDS round trip as the events, looked at in the shadow of a query's first node loads.
             const int lsl = lane < 32 ? CH_R2 : CH_R1;                     // lanes 0..31: window V - 2, lanes 32..63: window V - 1 (node order)
@@ -640,12 +697,20 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
             const long long nl = DENSE ? s_nlms : 0;
             const int dense_after = (int)((nl >> 9) > 8 ? ((nl >> 9) < 100000 ? (nl >> 9) : 100000) : 8);     // DENSE: node rounds before a query scans the log
             const ChWindow W = chain_window(n_idx[par], n_a[par], &s_wk[par], active, lane, n_type[par], n_px[par], n_py[par]);
-            const double o_dx = ONE ? c_dx : rlf64(c_dx, 0), o_dy = ONE ? c_dy : rlf64(c_dy, 0);     // lane 0's agent: drift at window start
-            const bool ownlane = W.v_inw && (ONE ? W.v_a : W.v_a % CH_AGW) + 1 == wave;
+            const double o_dx = c_dx, o_dy = c_dy;                                  // ONE: drift at window start
+            // !ONE: the state at window start of the lane's agent (any lane: the reads are unconditional, one round trip)
+            double st_dx = 0, st_dy = 0;
+            long long st_last = 0;
+            if (!ONE) { st_dx = s_dx[par][W.v_a]; st_dy = s_dy[par][W.v_a]; st_last = s_lastc[par][W.v_a]; }
+            const bool ownlane = W.v_inw && (ONE ? W.v_a + 1 : ev_own) == wave;
             // the lane's event may close if its agent is past its cool-down (:304); an agent that finds a match in
             // this window takes its later events off the list, so the state at window start decides for all of them
-            const long long lane_last = ONE ? c_last : (ownlane ? s_lastc[par][W.v_a] : 0);
+            const long long lane_last = ONE ? c_last : st_last;
             const bool may_close = ownlane && W.v_idx - lane_last >= min_between;
+            // !ONE: the state after the window, as far as it is known now: unchanged (a closure below overwrites its agent's)
+            double nw_dx = st_dx, nw_dy = st_dy;
+            long long nw_last = st_last;
+            if (!ONE && ownlane) { s_dx[par ^ 1][W.v_a] = st_dx; s_dy[par ^ 1][W.v_a] = st_dy; s_lastc[par ^ 1][W.v_a] = st_last; }
 #ifdef QS_CHAIN_PROF2
             const unsigned long long p2_t1 = __builtin_amdgcn_s_memtime();
             p2_head += p2_t1 - p2_t0;
@@ -656,9 +721,8 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
 #endif
                 const int src = __ffsll((long long)qrem) - 1;
                 const int qa = __builtin_amdgcn_readlane(W.v_a, src);
-                const int ql = ONE ? 0 : qa / CH_AGW;                               // the lane that keeps agent qa's state
                 const long long qidx = rl64(W.v_idx, src);
-                const double odx = ONE ? c_dx : rlf64(c_dx, ql), ody = ONE ? c_dy : rlf64(c_dy, ql);
+                const double odx = ONE ? c_dx : rlf64(st_dx, src), ody = ONE ? c_dy : rlf64(st_dy, src);   // agent qa's drift at window start
                 const double spx = rlf64(W.px, src), spy = rlf64(W.py, src);
                 const double qx = raw_pose ? spx : spx + odx;                         // rx += cdx  :856
                 const double qy = raw_pose ? spy : spy + ody;                         // ry += cdy  :857
@@ -789,7 +853,11 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
                     const double ex = wx - qx, ey = wy - qy;                                   // :311-312
                     const double cdx = ex * corr, cdy = ey * corr;                             // :314-315
                     const double ndx = odx + cdx, ndy = ody + cdy;                             // :911-914
-                    if (ONE || lane == ql) { c_dx = ndx; c_dy = ndy; c_last = qidx; }          // :318
+                    if (ONE) { c_dx = ndx; c_dy = ndy; c_last = qidx; }                         // :318
+                    else {
+                        if (lane == 0) { s_dx[par ^ 1][qa] = ndx; s_dy[par ^ 1][qa] = ndy; s_lastc[par ^ 1][qa] = qidx; }   // (after the carry-over above)
+                        if (ownlane && W.v_a == qa) { nw_dx = ndx; nw_dy = ndy; nw_last = qidx; }
+                    }
                 }
 #ifdef QS_CHAIN_PROF
                 { const unsigned long long tq3 = __builtin_amdgcn_s_memtime(); pq_a += tq1 - tq0; pq_b += tq2 - tq1; pq_c += tq3 - tq2; }
@@ -801,7 +869,7 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
 #ifdef QS_CHAIN_PROF2
             const unsigned long long p2_t2 = __builtin_amdgcn_s_memtime();
 #endif
-            if (active && own < nb) { s_dx[par ^ 1][own] = c_dx; s_dy[par ^ 1][own] = c_dy; s_lastc[par ^ 1][own] = c_last; }   // (ONE: lane 0)
+            if (ONE && active && lane == 0) { s_dx[par ^ 1][wave - 1] = c_dx; s_dy[par ^ 1][wave - 1] = c_dy; s_lastc[par ^ 1][wave - 1] = c_last; }
             // the window's landmarks get their final pose from their agent's owner: the drift at window start,
             // or -- later events of an agent that closed in this window -- the drift after the closure (:855-857)
             if (ONE) {                                                    // one agent per owner: its state is in lane 0
@@ -809,9 +877,8 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
                 const double ddx = after ? c_dx : o_dx, ddy = after ? c_dy : o_dy;
                 if (ownlane) { i_x[ring][lane] = raw_pose ? W.px : W.px + ddx; i_y[ring][lane] = raw_pose ? W.py : W.py + ddy; }
             } else if (ownlane) {
-                const int va = W.v_a;
-                const bool after = W.v_idx > s_lastc[par ^ 1][va];        // (own rows of the state, written just above)
-                const double ddx = after ? s_dx[par ^ 1][va] : s_dx[par][va], ddy = after ? s_dy[par ^ 1][va] : s_dy[par][va];
+                const bool after = W.v_idx > nw_last;
+                const double ddx = after ? nw_dx : st_dx, ddy = after ? nw_dy : st_dy;
                 i_x[ring][lane] = raw_pose ? W.px : W.px + ddx;
                 i_y[ring][lane] = raw_pose ? W.py : W.py + ddy;
             }
@@ -831,10 +898,12 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
 #ifdef QS_CHAIN_PROF3
         if (lane == 0) atomicAdd(&counters[wave == 1 ? QS_CNT_SLAM_MISC_ITERS : QS_CNT_EKF_WRAP_CLAMP], p3_busy);
 #endif
-        if (own < nb) {
-            drift[2 * (bot0 + own)] = c_dx;
-            drift[2 * (bot0 + own) + 1] = c_dy;
-            last_closure[bot0 + own] = c_last;
+        if (ONE) {
+            if (lane == 0) { drift[2 * (bot0 + wave - 1)] = c_dx; drift[2 * (bot0 + wave - 1) + 1] = c_dy; last_closure[bot0 + wave - 1] = c_last; }
+        } else if (own < nb) {                                // the states after the last window are in the buffer `par` names now
+            drift[2 * (bot0 + own)] = s_dx[par][own];
+            drift[2 * (bot0 + own) + 1] = s_dy[par][own];
+            last_closure[bot0 + own] = s_lastc[par][own];
         }
         if (lane == 0) {
 #if defined(QS_CHAIN_STATS) && !defined(QS_CHAIN_PROF2)
