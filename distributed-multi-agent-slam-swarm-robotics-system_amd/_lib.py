@@ -14,7 +14,7 @@ HEADER = os.path.join(os.path.dirname(_HERE), "include", "quasar_slam.h")
 
 QS_CNT_NAMES = ("datagrams", "accepted", "rays", "cells", "hits", "closures", "landmarks", "rebases",
                 "slam_windows", "slam_rounds", "slam_node_iters", "slam_misc_iters", "slam_cycles",
-                "slam_realtime_100mhz", "slam_cyc_prepare", "slam_cyc_query", "slam_cyc_commit", "ekf_wrap_clamp", "edge_rays")
+                "slam_realtime_100mhz", "slam_cyc_prepare", "slam_cyc_query", "slam_cyc_commit", "ekf_wrap_clamp", "edge_rays", "edge_overflow")
 QS_STAGE_NAMES = ("decode", "slam", "raycast", "ekf", "slam_chain", "rc_rays", "rc_sort", "rc_raster")
 UINT64_MAX = (1 << 64) - 1
 
@@ -112,6 +112,7 @@ SIGNATURES = {
     "qs_icp": (_i32, [_vp, _vp, _sz, _vp, _sz, _f64, _i32, _f64, _f64, _vp, _vp, _vp, _vp]),
     "qs_nn_search": (_i32, [_vp, _vp, _sz, _vp, _sz, _f64, _i32, _vp, _vp, _vp]),
     "qs_diag_mfma_f64_rate": (_i32, [_vp, C.POINTER(_f64)]),
+    "qs_diag_latencies": (_i32, [_vp, _vp]),
     "qs_voxel_downsample": (_i32, [_vp, _vp, _sz, _f64, _vp, _sz, C.POINTER(_sz)]),
     "qs_frontier_cells": (_i32, [_vp, _vp, _sz, C.POINTER(_sz)]),
     "qs_frontier_members": (_i32, [_vp, _vp, _sz, C.POINTER(_sz)]),

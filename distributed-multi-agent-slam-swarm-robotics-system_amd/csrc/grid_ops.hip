@@ -199,6 +199,36 @@ __global__ void qs_zone_identity_kernel(unsigned long long *zone, int n_bots)
         zone[4 * t + 2] = QS_ORD_MAX_IDENT; zone[4 * t + 3] = QS_ORD_MAX_IDENT;
     }
 }
+// qs_reset's small state in ONE launch (it was six memsets and a kernel, each a gap on the stream of a 2 ms step): drift,
+// zone boxes (identity), counters, per-graph batch counts, EKF state, flags
+__global__ void __launch_bounds__(256)
+qs_reset_small_kernel(double *__restrict__ drift, int n_drift, unsigned long long *__restrict__ zone, int n_bots,
+                      unsigned long long *__restrict__ counters, unsigned long long *__restrict__ graph_batch, int n_gb,
+                      double *__restrict__ ekf, int n_ekf, double *__restrict__ ekf_prev, int n_prev, unsigned int *__restrict__ flags)
+{
+    const int stride = gridDim.x * 256;
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < n_ekf; t += stride) ekf[t] = 0.0;
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < n_prev; t += stride) ekf_prev[t] = 0.0;
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < n_drift; t += stride) drift[t] = 0.0;
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < n_gb; t += stride) graph_batch[t] = 0ull;
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < n_bots; t += stride) {
+        zone[4 * t + 0] = QS_ORD_MIN_IDENT; zone[4 * t + 1] = QS_ORD_MIN_IDENT;
+        zone[4 * t + 2] = QS_ORD_MAX_IDENT; zone[4 * t + 3] = QS_ORD_MAX_IDENT;
+    }
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < QS_CNT_N) counters[threadIdx.x] = 0ull;
+        if (threadIdx.x < 4) flags[threadIdx.x] = 0u;
+    }
+}
+hipError_t qs_launch_reset_small(qs_ctx *c)
+{
+    const int nb = c->cfg.max_agent + 1;
+    const int n_ekf = nb * 44;
+    hipLaunchKernelGGL(qs_reset_small_kernel, dim3((n_ekf + 255) / 256), dim3(256), 0, c->stream, c->d_drift, nb * 2, c->d_zone, nb,
+                       c->d_counters, c->d_graph_batch, c->n_graphs * 2, c->d_ekf, n_ekf, c->d_ekf_prev, nb * 4, c->d_flags);
+    return hipGetLastError();
+}
+
 hipError_t qs_launch_fill_zone_identity(qs_ctx *c)
 {
     const int nb = c->cfg.max_agent + 1;

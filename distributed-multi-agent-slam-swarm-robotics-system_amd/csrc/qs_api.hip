@@ -8,6 +8,8 @@
 #include "qs_internal.h"
 
 static thread_local std::string g_create_err;
+static int flush_edge_rays(qs_ctx *c);      // exact-trig mode: rays waiting for libm end points (defined with the ingest path)
+#define FLUSHCHK(c) do { int rcf__ = flush_edge_rays(c); if (rcf__ != QS_OK) return rcf__; } while (0)
 
 static int qs_fail(qs_ctx *c, int code, const char *what, hipError_t e = hipSuccess)
 {
@@ -157,7 +159,6 @@ static int graph_reserve(qs_ctx *c, int g, long long need_lms, long long need_cl
 
 static int reset_state(qs_ctx *c)
 {
-    const int nb = c->cfg.max_agent + 1;
     HIPCHK(c, hipMemsetAsync(c->d_stamps, 0, c->cells * sizeof(unsigned int), c->stream));
     if (c->d_counts) HIPCHK(c, hipMemsetAsync(c->d_counts, 0, c->cells * sizeof(unsigned long long), c->stream));
     if (c->d_counts_fused) HIPCHK(c, hipMemsetAsync(c->d_counts_fused, 0, c->cells * sizeof(unsigned long long), c->stream));
@@ -165,12 +166,7 @@ static int reset_state(qs_ctx *c)
     if (c->d_dirty) HIPCHK(c, hipMemsetAsync(c->d_dirty, 0, c->dirty_words * sizeof(unsigned int), c->stream));
     if (c->d_counts_sent) HIPCHK(c, hipMemsetAsync(c->d_counts_sent, 0, c->cells * sizeof(unsigned long long), c->stream));
     c->sf_state = 0;
-    HIPCHK(c, hipMemsetAsync(c->d_drift, 0, (size_t)nb * 2 * sizeof(double), c->stream));
-    HIPCHK(c, qs_launch_fill_zone_identity(c));
-    HIPCHK(c, hipMemsetAsync(c->d_counters, 0, QS_CNT_N * sizeof(unsigned long long), c->stream));
-    HIPCHK(c, hipMemsetAsync(c->d_graph_batch, 0, (size_t)c->n_graphs * 2 * sizeof(unsigned long long), c->stream));
-    HIPCHK(c, hipMemsetAsync(c->d_ekf, 0, (size_t)nb * 44 * sizeof(double), c->stream));
-    HIPCHK(c, hipMemsetAsync(c->d_ekf_prev, 0, (size_t)nb * 4 * sizeof(double), c->stream));
+    HIPCHK(c, qs_launch_reset_small(c));      // drift, zone boxes, counters, per-graph batch counts, EKF state, flags: one launch
     // the bucket index of every graph: only what the session used of it (directory entries, first nodes,
     // pool nodes), found from the landmark log on the device; then the graphs' counters and the bots' last
     // closure (:271).  All enqueued: a reset does not wait for the GPU.
@@ -178,7 +174,7 @@ static int reset_state(qs_ctx *c)
     for (int g = 0; g < c->n_graphs; g++) { c->lms_upper[g] = 0; c->cls_upper[g] = 0; }
     c->next_seq = 0; c->epoch_base = 0; c->last_n = 0; c->last_has_poses = false; c->n_rebases = 0; c->edge_rays_total = 0;
     c->pile_mode = false;
-    HIPCHK(c, hipMemsetAsync(c->d_flags, 0, 2 * sizeof(unsigned int), c->stream));
+    c->edge_maybe = false; c->edge_overflow_total = 0;      // (rays still waiting belonged to the old session: the flags are cleared above)
     return QS_OK;
 }
 
@@ -235,8 +231,8 @@ extern "C" int qs_create(const qs_config *cfg, qs_ctx **out)
     CREATE_CHK(hipMalloc((void **)&c->d_graph_batch, (size_t)c->n_graphs * 2 * sizeof(unsigned long long)));
     CREATE_CHK(hipMalloc((void **)&c->d_ekf, (size_t)nb * 44 * sizeof(double)));
     CREATE_CHK(hipMalloc((void **)&c->d_ekf_prev, (size_t)nb * 4 * sizeof(double)));
-    CREATE_CHK(hipMalloc((void **)&c->d_flags, 2 * sizeof(unsigned int)));
-    CREATE_CHK(hipMemset(c->d_flags, 0, 2 * sizeof(unsigned int)));
+    CREATE_CHK(hipMalloc((void **)&c->d_flags, 4 * sizeof(unsigned int)));
+    CREATE_CHK(hipMemset(c->d_flags, 0, 4 * sizeof(unsigned int)));
     CREATE_CHK(hipMalloc((void **)&c->d_graphs, (size_t)c->n_graphs * sizeof(QsGraphDev)));
     CREATE_CHK(hipMemset(c->d_graphs, 0, (size_t)c->n_graphs * sizeof(QsGraphDev)));
     c->h_graphs.assign(c->n_graphs, QsGraphDev{});
@@ -262,7 +258,6 @@ static void free_batch(qs_ctx *c)
     hipFree(b.accept); hipFree(b.agent); hipFree(b.lm); hipFree(b.px); hipFree(b.py); hipFree(b.yaw);
     hipFree(b.dist); hipFree(b.enc); hipFree(b.rx); hipFree(b.ry); hipFree(b.hit); hipFree(b.hit_valid);
     if (b.map_ok != b.accept) hipFree(b.map_ok);
-    hipFree(b.edge);
     memset(&b, 0, sizeof b);
     QsSlamBatch &sb = c->sb;
     hipFree(sb.node); hipFree(sb.ev_node); hipFree(sb.ev_agent); hipFree(sb.ev_type); hipFree(sb.ev_px); hipFree(sb.ev_py);
@@ -283,6 +278,7 @@ extern "C" int qs_destroy(qs_ctx *c)
     hipFree(c->d_last_closure); hipFree(c->d_zone); hipFree(c->d_counters); hipFree(c->d_graph_batch);
     hipFree(c->d_ekf); hipFree(c->d_ekf_prev); hipFree(c->d_ekf_ws); hipFree(c->d_graphs); hipFree(c->d_flags); hipFree(c->d_pkts); hipFree(c->d_lens);
     hipFree(c->d_time); hipFree(c->d_bin_ws); hipFree(c->d_frontier_ws);
+    hipFree(c->d_edge);
     hipFree(c->d_dirty); hipFree(c->d_counts_sent); hipFree(c->d_sf_bitmaps); hipFree(c->d_sf_lists); hipFree(c->d_sf_counts); hipFree(c->d_sf_payload);
     for (auto &p : c->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (auto e : c->ev_pool) hipEventDestroy(e);
@@ -315,6 +311,7 @@ extern "C" int qs_sync(qs_ctx *c)
 {
     ARGCHK(c, c != nullptr);
     HIPCHK(c, hipSetDevice(c->device));
+    FLUSHCHK(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return QS_OK;
 }
@@ -379,7 +376,10 @@ static int ensure_batch(qs_ctx *c, size_t n)
         b.own_lo = c->cfg.shard_rank * c->cfg.shard_bots + 1;
         b.own_hi = std::min(c->cfg.max_agent, (c->cfg.shard_rank + 1) * c->cfg.shard_bots);
     } else { b.map_ok = b.accept; b.own_lo = 1; b.own_hi = c->cfg.max_agent; }
-    if (c->cfg.exact_trig) { HIPCHK(c, dev_realloc(&b.edge, 4 * cap)); b.edge_n = c->d_flags; }
+    if (c->cfg.exact_trig) {
+        if (!c->d_edge) HIPCHK(c, hipMalloc((void **)&c->d_edge, (size_t)QS_EDGE_CAP * sizeof(QsEdgeRec)));
+        b.edge = c->d_edge; b.edge_n = c->d_flags; b.edge_cap = QS_EDGE_CAP;
+    }
     QsSlamBatch &sb = c->sb;
     const size_t nblk = (size_t)qs_slam_blocks(cap), G = (size_t)c->n_graphs, nb = (size_t)c->cfg.max_agent + 2;
     HIPCHK(c, dev_realloc(&sb.node, cap)); HIPCHK(c, dev_realloc(&sb.ev_node, cap));
@@ -412,6 +412,7 @@ static int ensure_epoch(qs_ctx *c, uint64_t seq0, size_t n_seq)
         // qs_epoch_query before every ingest).
         if ((c->cfg.seq_stride > 1 || c->cfg.shard_bots > 0) && c->dirty_since_fuse)
             return qs_fail(c, QS_E_STATE, "this batch crosses a stamp epoch: fuse the shards' grids (all-reduce + qs_mark_fused) first");
+        { int rcf = flush_edge_rays(c); if (rcf != QS_OK) return rcf; }     // waiting rays carry stamps of the epoch that ends here
         HIPCHK(c, qs_launch_rebase(c));
         c->epoch_base = seq0 ? seq0 - 1 : 0;
         c->n_rebases++;
@@ -487,46 +488,53 @@ static int reserve_graphs_for_batch(qs_ctx *c, size_t n)
 }
 
 static int io_reserve(qs_ctx *c, size_t bytes);
-// Exact-trig mode (qs_config.exact_trig, default on): rays the device did not decide (raycast_common.h, qs_edge_ray) get
-// their end points from libm -- math.cos / math.sin of the reference are glibc's -- and are cast with the stamps the
-// ingest would have given them.  Costs one 4-byte read-back per ingest (the call then ends with a stream sync).
-static int resolve_edge_rays(qs_ctx *c, uint64_t seq0)
+// Exact-trig mode (qs_config.exact_trig, default on): rays the device did not decide (raycast_common.h, qs_edge_ray) wait in
+// a list of self-contained records (pose, distance, stamp) and get their end points from libm here -- math.cos / math.sin of
+// the reference are glibc's -- before they are cast with the stamps their ingest gave them (stamps make the order
+// irrelevant).  An ingest does not wait for this: the list is flushed at the next point where the map can be OBSERVED (any
+// call that reads or hands out the grid, the counters or the pose graphs; qs_sync; before a stamp rebase) and dropped by
+// qs_reset.  The same synchronisation brings the graphs' real landmark / closure counts (capacity planning starts from them,
+// not from "every record so far was a landmark") and the pile flag of the loop-closure chain.
+static int flush_edge_rays(qs_ctx *c)
 {
-    unsigned int fl[2] = {0, 0};
+    if (!c->edge_maybe) return QS_OK;
+    unsigned int fl[4] = {0, 0, 0, 0};
     HIPCHK(c, hipMemcpyAsync(fl, c->d_flags, sizeof fl, hipMemcpyDeviceToHost, c->stream));
-    // (the same synchronisation brings the graphs' real landmark / closure counts: capacity planning starts from them, not from
-    // "every record so far was a landmark" -- ADVICE r1)
     std::vector<QsGraphDev> cur((size_t)c->n_graphs);
     HIPCHK(c, hipMemcpyAsync(cur.data(), c->d_graphs, cur.size() * sizeof(QsGraphDev), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->edge_maybe = false;
     for (int g = 0; g < c->n_graphs; g++) { c->lms_upper[g] = cur[g].n_lms; c->cls_upper[g] = cur[g].n_cls; }
-    const unsigned int n_edge = fl[0];
     if (fl[1]) c->pile_mode = true;                      // a landmark pile has formed: the chain kernel's DENSE variant from now on
-    c->edge_rays_total += n_edge;
+    const unsigned int n_edge = fl[0] < QS_EDGE_CAP ? fl[0] : QS_EDGE_CAP;
+    c->edge_overflow_total += fl[2];
     if (n_edge == 0) return QS_OK;
-    const size_t bytes = (size_t)n_edge * 5 * sizeof(double);
+    c->edge_rays_total += n_edge;
+    std::vector<QsEdgeRec> recs(n_edge);
+    HIPCHK(c, hipMemcpy(recs.data(), c->d_edge, (size_t)n_edge * sizeof(QsEdgeRec), hipMemcpyDeviceToHost));
+    const size_t bytes = (size_t)n_edge * 4 * sizeof(double);
     int rc = io_reserve(c, bytes);
     if (rc != QS_OK) return rc;
     double *d = (double *)c->d_io_ws;
-    std::vector<double> h((size_t)n_edge * 5);
-    HIPCHK(c, qs_launch_edge_gather(c, n_edge, d));
-    HIPCHK(c, hipMemcpyAsync(h.data(), d, bytes, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    std::vector<unsigned int> ids(n_edge);
-    HIPCHK(c, hipMemcpy(ids.data(), c->b.edge, n_edge * sizeof(unsigned int), hipMemcpyDeviceToHost));
+    std::vector<double> h((size_t)n_edge * 4);
     static const double kPi = 3.141592653589793;                                              // math.pi
     static const double off[4] = {0.0, kPi / 2, kPi, -kPi / 2};                               // :61-66
     for (unsigned int e = 0; e < n_edge; e++) {
-        const double rx = h[5 * e], ry = h[5 * e + 1], yaw = h[5 * e + 2], dd = h[5 * e + 3];
-        const double a = yaw + off[ids[e] & 3];                                                // :887
+        const QsEdgeRec &r = recs[e];
+        const double dd = (double)r.d;
+        const int sensor = (int)(((r.key_free >> 1) - 1) & 3);                                 // ordinal = 4 * arrival index + sensor + 1
+        const double a = r.yaw + off[sensor];                                                  // :887
         const bool valid = (c->cfg.min_dist < dd) && (dd <= c->cfg.max_dist);                  // :888
         const double range = valid ? dd : ((dd > c->cfg.min_dist) ? ((c->cfg.max_dist < dd) ? c->cfg.max_dist : dd) : c->cfg.max_dist);   // :900
-        h[5 * e + 2] = rx + range * cos(a);                                                    // :890 / :901
-        h[5 * e + 3] = ry + range * sin(a);                                                    // :891 / :902
-        h[5 * e + 4] = valid ? 1.0 : 0.0;
+        h[4 * e] = r.rx + range * cos(a);                                                      // :890 / :901
+        h[4 * e + 1] = r.ry + range * sin(a);                                                  // :891 / :902
+        h[4 * e + 2] = valid ? 1.0 : 0.0;
+        h[4 * e + 3] = 0.0;
     }
     HIPCHK(c, hipMemcpyAsync(d, h.data(), bytes, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, qs_launch_edge_cast(c, n_edge, d, seq0));
+    HIPCHK(c, qs_launch_edge_cast(c, n_edge, d));
+    HIPCHK(c, hipMemsetAsync(c->d_flags, 0, sizeof(unsigned int), c->stream));                 // the list is empty again
+    HIPCHK(c, hipMemsetAsync(c->d_flags + 2, 0, sizeof(unsigned int), c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));                                                // h goes out of scope
     return QS_OK;
 }
@@ -557,7 +565,6 @@ static int ingest_device(qs_ctx *c, const uint8_t *d_pkts, size_t n, size_t stri
     if (rc != QS_OK) return rc;
     HIPCHK(c, hipMemsetAsync(c->d_graph_batch, 0, (size_t)c->n_graphs * 2 * sizeof(unsigned long long), c->stream));
     HIPCHK(c, hipMemsetAsync(c->sb.agent_ev, 0, ((size_t)c->cfg.max_agent + 2) * sizeof(unsigned int), c->stream));
-    if (c->b.edge_n) HIPCHK(c, hipMemsetAsync(c->b.edge_n, 0, sizeof(unsigned int), c->stream));
     { StageTimer t(c, QS_STAGE_DECODE); HIPCHK(c, qs_launch_decode(c, d_pkts, n, stride, d_lens)); t.stop(); }
     rc = reserve_graphs_for_batch(c, n);
     if (rc != QS_OK) return rc;
@@ -585,7 +592,7 @@ static int ingest_device(qs_ctx *c, const uint8_t *d_pkts, size_t n, size_t stri
         t.stop();
     }
     if (c->cfg.enable_ekf) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_ekf_done, 0));   // join
-    if (c->b.edge) { rc = resolve_edge_rays(c, seq0); if (rc != QS_OK) return rc; }
+    if (c->b.edge) c->edge_maybe = true;                 // resolved at the next point the map is observed (flush_edge_rays)
     c->next_seq = seq0 + n * sstride;
     c->dirty_since_fuse = true;
     return QS_OK;
@@ -622,14 +629,14 @@ extern "C" int qs_ingest(qs_ctx *c, const uint8_t *pkts, size_t n, size_t stride
     if (recv_time) HIPCHK(c, hipMemcpyAsync(c->d_time, recv_time, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
     int rc = ingest_device(c, c->d_pkts, n, stride, lens ? c->d_lens : nullptr, recv_time ? c->d_time : nullptr, seq0);
     if (rc != QS_OK) return rc;
-    // this call waits for the GPU anyway: take the graphs' real landmark / closure counts along, so that the capacity
-    // planning of the next batches starts from them and not from "every record so far was a landmark"
+    // this call waits for the GPU anyway (the caller's buffers are free when it returns): the waiting edge rays are resolved
+    // now, and the graphs' real landmark / closure counts and the pile flag come along
+    if (c->cfg.exact_trig) { c->edge_maybe = true; return flush_edge_rays(c); }
     std::vector<QsGraphDev> cur((size_t)c->n_graphs);
     HIPCHK(c, hipMemcpyAsync(cur.data(), c->d_graphs, cur.size() * sizeof(QsGraphDev), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (int g = 0; g < c->n_graphs; g++) { c->lms_upper[g] = cur[g].n_lms; c->cls_upper[g] = cur[g].n_cls; }
-    if (!c->cfg.exact_trig) return read_pile_flag(c);
-    return QS_OK;
+    return read_pile_flag(c);
 }
 
 extern "C" int qs_last_batch(qs_ctx *c, uint8_t *accepted, double *pose, size_t n)
@@ -738,6 +745,7 @@ extern "C" int qs_grid_i8_device(qs_ctx *c, int8_t *out_dev)
 {
     ARGCHK(c, c != nullptr && out_dev != nullptr);
     HIPCHK(c, hipSetDevice(c->device));
+    FLUSHCHK(c);
     HIPCHK(c, qs_launch_view_i8(c, (signed char *)out_dev));
     return QS_OK;
 }
@@ -746,6 +754,7 @@ extern "C" int qs_grid_i8(qs_ctx *c, int8_t *out_host)
 {
     ARGCHK(c, c != nullptr && out_host != nullptr);
     HIPCHK(c, hipSetDevice(c->device));
+    FLUSHCHK(c);
     signed char *d = nullptr;
     HIPCHK(c, hipMalloc((void **)&d, c->cells));
     hipError_t e = qs_launch_view_i8(c, d);
@@ -761,6 +770,7 @@ extern "C" int qs_grid_counts(qs_ctx *c, int32_t *hits_host, int32_t *misses_hos
     ARGCHK(c, c != nullptr && hits_host && misses_host);
     if (!c->d_counts) return qs_fail(c, QS_E_INVAL, "qs_grid_counts: context created with enable_counts = 0");
     HIPCHK(c, hipSetDevice(c->device));
+    FLUSHCHK(c);
     int *d = nullptr;
     HIPCHK(c, hipMalloc((void **)&d, 2 * c->cells * sizeof(int)));
     hipError_t e = qs_launch_split_counts(c, d, d + c->cells);
@@ -777,6 +787,7 @@ extern "C" int qs_grid_logodds(qs_ctx *c, float l_occ, float l_free, float lmin,
     ARGCHK(c, c != nullptr && out_host);
     if (!c->d_counts) return qs_fail(c, QS_E_INVAL, "qs_grid_logodds: context created with enable_counts = 0");
     HIPCHK(c, hipSetDevice(c->device));
+    FLUSHCHK(c);
     float *d = nullptr;
     HIPCHK(c, hipMalloc((void **)&d, c->cells * sizeof(float)));
     hipError_t e = qs_launch_logodds(c, l_occ, l_free, lmin, lmax, d);
@@ -790,6 +801,8 @@ extern "C" int qs_grid_logodds(qs_ctx *c, float l_occ, float l_free, float lmin,
 extern "C" int qs_device_buffers(qs_ctx *c, void **stamps_dev, size_t *stamps_bytes, void **counts_dev, size_t *counts_bytes)
 {
     ARGCHK(c, c != nullptr);
+    HIPCHK(c, hipSetDevice(c->device));
+    FLUSHCHK(c);                                   // whoever gets the buffers may read them (a collective)
     if (stamps_dev) *stamps_dev = c->d_stamps;
     if (stamps_bytes) *stamps_bytes = c->cells * sizeof(unsigned int);
     if (counts_dev) *counts_dev = c->d_counts;
@@ -1011,6 +1024,7 @@ extern "C" int qs_fused_counts(qs_ctx *c, void **fused_dev, size_t *bytes)
     if (!c->d_counts) return qs_fail(c, QS_E_INVAL, "qs_fused_counts: context created with enable_counts = 0");
     if (c->d_dirty) return qs_fail(c, QS_E_STATE, "qs_fused_counts: dirty tracking is on -- the fused counters accumulate the sparse fuse's deltas");
     HIPCHK(c, hipSetDevice(c->device));
+    FLUSHCHK(c);
     const size_t nb = c->cells * sizeof(unsigned long long);
     if (!c->d_counts_fused) HIPCHK(c, hipMalloc((void **)&c->d_counts_fused, nb));
     HIPCHK(c, hipMemcpyAsync(c->d_counts_fused, c->d_counts, nb, hipMemcpyDeviceToDevice, c->stream));
@@ -1074,6 +1088,7 @@ extern "C" int qs_dirty_blocks(qs_ctx *c, size_t *n_blocks, size_t *block_cells)
     ARGCHK(c, c != nullptr && n_blocks != nullptr);
     if (!c->d_dirty) return qs_fail(c, QS_E_STATE, "qs_dirty_blocks: dirty tracking is off (qs_dirty_tracking)");
     HIPCHK(c, hipSetDevice(c->device));
+    FLUSHCHK(c);
     int rc = io_reserve(c, sizeof(unsigned long long));
     if (rc != QS_OK) return rc;
     unsigned long long v = 0;
@@ -1091,6 +1106,7 @@ extern "C" int qs_sparse_fuse_begin(qs_ctx *c, int32_t world, int32_t rank, void
     ARGCHK(c, world >= 1 && world <= QS_SPARSE_MAX_WORLD && rank >= 0 && rank < world);
     if (!c->d_dirty) return qs_fail(c, QS_E_STATE, "qs_sparse_fuse_begin: dirty tracking is off (qs_dirty_tracking)");
     HIPCHK(c, hipSetDevice(c->device));
+    FLUSHCHK(c);
     if (world != c->sf_world) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
         HIPCHK(c, dev_realloc(&c->d_sf_bitmaps, (size_t)world * c->dirty_words));
@@ -1159,6 +1175,7 @@ extern "C" int qs_fuse(qs_ctx *dst, qs_ctx *const *srcs, size_t n)
             return qs_fail(dst, QS_E_INVAL, "qs_fuse: source grids must share device and geometry with dst");
         if (s->epoch_base != dst->epoch_base || s->n_rebases != dst->n_rebases)
             return qs_fail(dst, QS_E_INVAL, "qs_fuse: source and destination are in different stamp epochs");
+        { HIPCHK(dst, hipSetDevice(s->device)); int rcs = flush_edge_rays(s); if (rcs != QS_OK) return qs_fail(dst, rcs, s->err.c_str()); }
         HIPCHK(dst, hipStreamSynchronize(s->stream));
         st[i] = s->d_stamps; ct[i] = s->d_counts;
         if (!s->d_counts) counts = false;
@@ -1396,6 +1413,33 @@ extern "C" int qs_diag_mfma_f64_rate(qs_ctx *c, double *tflops)
     return QS_OK;
 }
 
+// Diagnostic: measured latencies of the primitives of one loop-closure decision (diag.hip), shader-clock cycles.
+extern "C" int qs_diag_latencies(qs_ctx *c, double out[QS_DIAG_LAT_N])
+{
+    ARGCHK(c, c != nullptr && out != nullptr);
+    HIPCHK(c, hipSetDevice(c->device));
+    const unsigned int n2 = 1u << 18, n1 = 1u << 11;            // 1 MiB: past the 32 KiB L1, inside the 4 MiB L2; 8 KiB: inside L1
+    std::vector<unsigned int> h2(n2), h1(n1);
+    for (unsigned int k = 0; k < n2; k++) h2[k] = (k * 1664525u + 1013904223u) & (n2 - 1);     // full-period LCG: one cycle through all entries
+    for (unsigned int k = 0; k < n1; k++) h1[k] = (k * 1664525u + 1013904223u) & (n1 - 1);
+    unsigned int *d2 = nullptr, *d1 = nullptr; double *d_out = nullptr;
+    double h_out[16] = {0};
+    hipError_t e = hipMalloc((void **)&d2, n2 * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&d1, n1 * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_out, sizeof h_out);
+    if (e == hipSuccess) e = hipMemcpyAsync(d2, h2.data(), n2 * 4, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d1, h1.data(), n1 * 4, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_out, 0, sizeof h_out, c->stream);
+    if (e == hipSuccess) e = qs_launch_diag_latencies(c, d2, d1, d_out);          // (warm: code load)
+    if (e == hipSuccess) e = qs_launch_diag_latencies(c, d2, d1, d_out);
+    if (e == hipSuccess) e = hipMemcpyAsync(h_out, d_out, sizeof h_out, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(d2); hipFree(d1); hipFree(d_out);
+    if (e != hipSuccess) return qs_fail(c, QS_E_HIP, "qs_diag_latencies", e);
+    for (int i = 0; i < QS_DIAG_LAT_N; i++) out[i] = h_out[i];
+    return QS_OK;
+}
+
 extern "C" int qs_voxel_downsample(qs_ctx *c, const double *xy, size_t n, double voxel, double *out_xy, size_t cap, size_t *n_out)
 {
     ARGCHK(c, c != nullptr && n_out != nullptr && voxel > 0);
@@ -1436,6 +1480,7 @@ static int frontier_run(qs_ctx *c, int mode, int32_t min_cluster, int32_t *xy, i
 {
     ARGCHK(c, c != nullptr && n_out != nullptr);
     HIPCHK(c, hipSetDevice(c->device));
+    FLUSHCHK(c);
     if (!c->d_frontier_ws) HIPCHK(c, hipMalloc(&c->d_frontier_ws, qs_frontier_workspace_bytes(c)));
     void *ws = c->d_frontier_ws;
     HIPCHK(c, qs_launch_frontier_label(c, ws, mode != 0));
@@ -1553,11 +1598,13 @@ extern "C" int qs_counters(qs_ctx *c, uint64_t out[QS_CNT_N])
 {
     ARGCHK(c, c != nullptr && out);
     HIPCHK(c, hipSetDevice(c->device));
+    FLUSHCHK(c);
     unsigned long long v[QS_CNT_N];
     HIPCHK(c, hipMemcpyAsync(v, c->d_counters, sizeof v, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (int i = 0; i < QS_CNT_N; i++) out[i] = v[i];
     out[QS_CNT_REBASES] = c->n_rebases;
     out[QS_CNT_EDGE_RAYS] = c->edge_rays_total;
+    out[QS_CNT_EDGE_OVERFLOW] = c->edge_overflow_total;
     return QS_OK;
 }

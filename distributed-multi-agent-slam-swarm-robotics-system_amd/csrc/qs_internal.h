@@ -93,6 +93,10 @@ struct QsGeom {
 __host__ __device__ inline size_t qs_dirty_word(int x, int y, int pitch) { return (size_t)(y / QS_DIRTY_BLOCK_H) * pitch + (x / QS_DIRTY_BLOCK_W) / 32; }
 __host__ __device__ inline unsigned int qs_dirty_mask(int x) { return 1u << ((x / QS_DIRTY_BLOCK_W) & 31); }
 
+// a ray left to the host (exact-trig mode): everything needed to cast it later, whatever has happened to its batch since
+struct QsEdgeRec { double rx, ry, yaw; float d; unsigned int key_free; };     // key_free: stamp of its free cells ((ordinal << 1) | 0)
+#define QS_EDGE_CAP (1u << 18)
+
 // ---- decoded batch (SoA, one slot per datagram of the batch) -----------------------------
 struct QsBatch {
     size_t n;
@@ -100,8 +104,10 @@ struct QsBatch {
     unsigned char *map_ok;   // 1 = accepted AND this context casts its rays / runs its filter: the same array as accept
                              // unless the context is one shard of a replicated-pose-graph deployment (qs_config.shard_bots)
     int own_lo, own_hi;      // agents whose rays this context casts (1..max_agent when not sharded)
-    unsigned int *edge;      // exact-trig mode: rays (4 * record + sensor) whose end point lies within 1e-9 cells of a cell
-    unsigned int *edge_n;    //   boundary are not cast by the device but listed here; the host resolves them (qs_api.hip)
+    QsEdgeRec *edge;         // exact-trig mode: rays whose end point lies within 1e-9 cells of a cell boundary are not cast by the
+    unsigned int *edge_n;    //   device but appended here, self-contained (pose, distance, stamp): the host resolves them at the next
+    unsigned int edge_cap;   //   point the map is observed (qs_api.hip: flush_edge_rays); edge_n[0] = records so far, [2] = rays that
+                             //   found the list full and were cast with the device's trig after all
     unsigned char *agent;    // agent_id
     unsigned char *lm;       // landmark_type (0 for v1 packets)
     double *px, *py, *yaw;   // f32 fields widened; px already has the bot offset (:851-852)
@@ -175,9 +181,13 @@ struct qs_ctx {
     void *d_ekf_ws = nullptr; size_t ekf_ws_bytes = 0;   // parallel-in-time EKF workspace (ekf_scan.hip)
 
     uint64_t next_seq = 0, epoch_base = 0, n_rebases = 0;
-    unsigned int *d_flags = nullptr;             // [0] edge rays of the batch (exact-trig mode), [1] a landmark pile has formed (slam.hip, DENSE)
+    unsigned int *d_flags = nullptr;             // [0] edge rays waiting for the host (exact-trig mode), [1] a landmark pile has formed
+                                                 // (slam.hip, DENSE), [2] edge rays that found the list full, [3] spare
+    QsEdgeRec *d_edge = nullptr;                 // [QS_EDGE_CAP] the waiting rays
+    bool edge_maybe = false;                     // an exact-trig ingest has run since the last flush: the list may hold rays
     bool pile_mode = false;                      // launch the chain kernel's DENSE variant
     uint64_t edge_rays_total = 0;                // exact-trig mode: rays resolved on the host since the last reset
+    uint64_t edge_overflow_total = 0;            //   ... and rays that found the list full (cast with the device's trig)
 
     // timing
     bool timing = false;
@@ -215,8 +225,7 @@ int qs_slam_blocks(size_t n);
 // raycast.hip
 #define QS_DIRECT_MAX_BATCH 256   // raycast_mode auto: batches up to this size take the direct kernel
 hipError_t qs_launch_raycast_direct(qs_ctx *c, size_t n, uint64_t seq0);
-hipError_t qs_launch_edge_gather(qs_ctx *c, unsigned int n_edge, double *d_out);
-hipError_t qs_launch_edge_cast(qs_ctx *c, unsigned int n_edge, const double *d_in, uint64_t seq0);
+hipError_t qs_launch_edge_cast(qs_ctx *c, unsigned int n_edge, const double *d_in);
 hipError_t qs_launch_hits(qs_ctx *c, size_t n);                 // ray end points of the resident batch (qs_last_hits)
 hipError_t qs_launch_update_rays(qs_ctx *c, const double *rx, const double *ry, const double *hx,
                                  const double *hy, const unsigned char *valid, size_t n,
@@ -235,6 +244,7 @@ hipError_t qs_launch_fuse(qs_ctx *c, const unsigned int *const *d_src_stamps,
                           const unsigned long long *const *d_src_counts, size_t n_src, size_t cell_off, size_t n_cells,
                           unsigned long long *dst_counts);
 hipError_t qs_launch_fill_zone_identity(qs_ctx *c);
+hipError_t qs_launch_reset_small(qs_ctx *c);
 hipError_t qs_launch_grid_to_pcd(qs_ctx *c, const signed char *d_grid, int h, int w, double res,
                                  double ox, double oy, double *d_xy, size_t cap,
                                  unsigned long long *d_count, unsigned int *d_rowcount);
@@ -248,6 +258,8 @@ hipError_t qs_launch_sf_lists(qs_ctx *c);
 hipError_t qs_launch_sf_pack(qs_ctx *c, unsigned int n_own, unsigned char *dst);
 hipError_t qs_launch_sf_apply(qs_ctx *c);
 hipError_t qs_launch_sf_popcount(qs_ctx *c, unsigned long long *d_out);
+// diag.hip
+hipError_t qs_launch_diag_latencies(qs_ctx *c, const unsigned int *d_chase_l2, const unsigned int *d_chase_l1, double *d_out);
 // frontier.hip
 size_t qs_frontier_workspace_bytes(const qs_ctx *c);
 hipError_t qs_launch_frontier_label(qs_ctx *c, void *ws, bool with_clusters);

@@ -45,8 +45,8 @@ qs_raycast_direct_kernel(size_t n, QsBatch b, QsGeom geo, unsigned int *__restri
         my_ray = 1;
         const unsigned int key_free = (unsigned int)((ord_base + ord_stride * i + s + 1) << 1);
         QsLine ln;
-        if (b.edge && qs_edge_ray(ray, geo)) {
-            b.edge[atomicAdd(b.edge_n, 1u)] = (unsigned int)(4 * i + s);            // the host decides this ray's cells
+        if (b.edge && qs_edge_ray(ray, geo) && qs_edge_defer(b, rx, ry, yaw, df, key_free)) {
+            // the host decides this ray's cells (qs_api.hip: flush_edge_rays)
         } else if (qs_line_setup(ray, rx, ry, geo, ln)) {
             int x = ln.x0, y = ln.y0, err = ln.dx - ln.dy;
             for (;;) {
@@ -148,30 +148,21 @@ hipError_t qs_launch_update_rays(qs_ctx *c, const double *rx, const double *ry, 
     return hipGetLastError();
 }
 
-// ---- exact-trig mode: the listed rays' inputs out, their host-computed end points back in ---------------------
-__global__ void qs_edge_gather_kernel(unsigned int n_edge, QsBatch b, double *__restrict__ out /* [n_edge][5]: rx, ry, yaw, d, - */)
-{
-    const unsigned int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n_edge) return;
-    const unsigned int r = b.edge[e], i = r >> 2;
-    out[5 * e] = b.rx[i]; out[5 * e + 1] = b.ry[i]; out[5 * e + 2] = b.yaw[i]; out[5 * e + 3] = (double)((const float *)b.dist)[r];
-    out[5 * e + 4] = 0.0;
-}
-// the cells of ray e (end point from the host) with the stamp the ingest would have given it
+// ---- exact-trig mode: the waiting rays cast with their host-computed end points --------------------------------------
+// in: [n_edge][4] = ex, ey, hit_valid, -  (end point from libm on the host); pose and stamp come from the ray's record
 template <bool COUNTS>
-__global__ void qs_edge_cast_kernel(unsigned int n_edge, QsBatch b, const double *__restrict__ in /* [n_edge][5]: rx, ry, ex, ey, hit_valid */,
+__global__ void qs_edge_cast_kernel(unsigned int n_edge, const QsEdgeRec *__restrict__ recs, const double *__restrict__ in,
                                     QsGeom geo, unsigned int *__restrict__ stamps, unsigned long long *__restrict__ counts,
-                                    unsigned long long ord_base, unsigned long long ord_stride, unsigned long long *__restrict__ counters)
+                                    unsigned long long *__restrict__ counters)
 {
     const unsigned int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_edge) return;
-    const unsigned int r = b.edge[e];
-    const size_t i = r >> 2; const int s = (int)(r & 3);
-    QsRay ray; ray.ex = in[5 * e + 2]; ray.ey = in[5 * e + 3]; ray.valid = in[5 * e + 4] != 0.0;
-    const unsigned int key_free = (unsigned int)((ord_base + ord_stride * i + s + 1) << 1);
+    const QsEdgeRec rec = recs[e];
+    QsRay ray; ray.ex = in[4 * e]; ray.ey = in[4 * e + 1]; ray.valid = in[4 * e + 2] != 0.0;
+    const unsigned int key_free = rec.key_free;
     QsLine ln;
     unsigned int cells = 0;
-    if (qs_line_setup(ray, in[5 * e], in[5 * e + 1], geo, ln)) {
+    if (qs_line_setup(ray, rec.rx, rec.ry, geo, ln)) {
         int x = ln.x0, y = ln.y0, err = ln.dx - ln.dy;
         for (;;) {
             const bool last = (x == ln.x1 && y == ln.y1);
@@ -190,21 +181,14 @@ __global__ void qs_edge_cast_kernel(unsigned int n_edge, QsBatch b, const double
     }
     if (cells) atomicAdd(&counters[QS_CNT_CELLS], (unsigned long long)cells);
 }
-hipError_t qs_launch_edge_gather(qs_ctx *c, unsigned int n_edge, double *d_out)
+hipError_t qs_launch_edge_cast(qs_ctx *c, unsigned int n_edge, const double *d_in)
 {
-    hipLaunchKernelGGL(qs_edge_gather_kernel, dim3((n_edge + 255) / 256), dim3(256), 0, c->stream, n_edge, c->b, d_out);
-    return hipGetLastError();
-}
-hipError_t qs_launch_edge_cast(qs_ctx *c, unsigned int n_edge, const double *d_in, uint64_t seq0)
-{
-    const unsigned long long ord_base = 4ull * (seq0 - c->epoch_base);
-    const unsigned long long ord_stride = 4ull * (unsigned long long)(c->cfg.seq_stride > 0 ? c->cfg.seq_stride : 1);
     if (c->cfg.enable_counts)
-        hipLaunchKernelGGL(qs_edge_cast_kernel<true>, dim3((n_edge + 255) / 256), dim3(256), 0, c->stream, n_edge, c->b, d_in, c->geom,
-                           c->d_stamps, c->d_counts, ord_base, ord_stride, c->d_counters);
+        hipLaunchKernelGGL(qs_edge_cast_kernel<true>, dim3((n_edge + 255) / 256), dim3(256), 0, c->stream, n_edge, c->d_edge, d_in, c->geom,
+                           c->d_stamps, c->d_counts, c->d_counters);
     else
-        hipLaunchKernelGGL(qs_edge_cast_kernel<false>, dim3((n_edge + 255) / 256), dim3(256), 0, c->stream, n_edge, c->b, d_in, c->geom,
-                           c->d_stamps, c->d_counts, ord_base, ord_stride, c->d_counters);
+        hipLaunchKernelGGL(qs_edge_cast_kernel<false>, dim3((n_edge + 255) / 256), dim3(256), 0, c->stream, n_edge, c->d_edge, d_in, c->geom,
+                           c->d_stamps, c->d_counts, c->d_counters);
     return hipGetLastError();
 }
 

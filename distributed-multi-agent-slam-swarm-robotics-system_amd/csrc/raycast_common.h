@@ -88,6 +88,16 @@ __device__ inline bool qs_edge_ray(const QsRay &ray, const QsGeom &geo)
     return qs_edge_coord(ray.ex, geo.ox, geo) || qs_edge_coord(ray.ey, geo.oy, geo);
 }
 
+// leave the ray to the host; false: the list is full (the caller casts the ray with the device's end point after all)
+__device__ inline bool qs_edge_defer(const QsBatch &b, double rx, double ry, double yaw, float d, unsigned int key_free)
+{
+    const unsigned int slot = atomicAdd(b.edge_n, 1u);
+    if (slot >= b.edge_cap) { atomicAdd(b.edge_n + 2, 1u); return false; }
+    QsEdgeRec rec; rec.rx = rx; rec.ry = ry; rec.yaw = yaw; rec.d = d; rec.key_free = key_free;
+    b.edge[slot] = rec;
+    return true;
+}
+
 struct QsLine { int x0, y0, x1, y1, dx, dy, sx, sy; };
 
 // Grid end points of a ray and the Bresenham set-up of :158-165.  Returns false when no cell

@@ -129,8 +129,9 @@ qs_rays_kernel(size_t n, QsBatch b, QsGeom geo, QtWorkspace ws, unsigned int *__
             my_hits += valid ? 1u : 0u;
             my_rays++;
             QsLine ln;
-            if (b.edge && qs_edge_ray(ray, geo)) {
-                b.edge[atomicAdd(b.edge_n, 1u)] = (unsigned int)r;                  // 4 * record + sensor: the host decides this ray's cells
+            if (b.edge && qs_edge_ray(ray, geo) &&
+                qs_edge_defer(b, rx, ry, yaw, df, (unsigned int)((ord_base + ord_stride * i + s + 1) << 1))) {
+                // the host decides this ray's cells (qs_api.hip: flush_edge_rays)
             } else if (qs_line_setup(ray, rx, ry, geo, ln)) {
                 if (ln.dx < QT_TILE && ln.dy < QT_TILE) {
                     // the ray's cells lie in at most 2 x 2 tiles

@@ -386,6 +386,15 @@ class QuasarMapper:
         self._chk(self._L.qs_diag_mfma_f64_rate(self._h, C.byref(v)), "qs_diag_mfma_f64_rate")
         return v.value
 
+    def diag_latencies(self):
+        """Measured latencies (shader-clock cycles) of the primitives a loop-closure decision chains together, by one
+        workgroup on this GPU: dict with l2_load, l1_load, lds_read, fma_f64, dpp_step, readlane_step, barrier_16_waves,
+        barrier_5_waves, clock_mhz."""
+        out = np.zeros(9, dtype=np.float64)
+        self._chk(self._L.qs_diag_latencies(self._h, _ptr(out)), "qs_diag_latencies")
+        names = ("l2_load", "l1_load", "lds_read", "fma_f64", "dpp_step", "readlane_step", "barrier_16_waves", "barrier_5_waves", "clock_mhz")
+        return dict(zip(names, (float(v) for v in out)))
+
     def voxel_downsample(self, xy, voxel):
         a = np.ascontiguousarray(xy, dtype=np.float64)
         n = C.c_size_t()

@@ -67,8 +67,10 @@ typedef struct qs_config {
     int32_t shard_rank;
     int32_t exact_trig;         /* 1 (default): rays whose end point falls within 1e-9 cells of a cell boundary -- where a last-bit
                                    difference between the device's sin / cos and glibc's (CPython's math.cos / math.sin) could
-                                   change a cell index -- are resolved on the host with libm; every ingest then ends with one
-                                   stream synchronisation.  0: device trig only, qs_ingest_device stays asynchronous */
+                                   change a cell index -- are not cast by the device but wait, self-contained, for the host to
+                                   recompute their end points with libm: at the next call that observes the map (grid / counter /
+                                   frontier reads, qs_device_buffers, a fuse, qs_counters, qs_sync).  qs_ingest_device itself never
+                                   waits for the GPU.  0: device trig only */
     int32_t reserved[3];
 } qs_config;
 
@@ -227,6 +229,13 @@ int qs_nn_search(qs_ctx *ctx, const double *src_xy, size_t n_src, const double *
                  double max_dist, int32_t mode, int32_t *corr, double *d2, float ms[2]);
 /* diagnostic: measured dense fp64 MFMA rate of this GPU (TFLOP/s), the ceiling qs_nn_search mode 2 is priced against */
 int qs_diag_mfma_f64_rate(qs_ctx *ctx, double *tflops);
+/* diagnostic: latencies of the primitives one loop-closure decision chains together, measured on this GPU by ONE workgroup
+ * (as qs_slam_chain_kernel runs), in shader-clock cycles:
+ *   out[0] dependent global load, L2 hit     out[1] dependent global load, L1 hit     out[2] dependent LDS read
+ *   out[3] dependent v_fma_f64               out[4] dependent DPP / VALU step          out[5] v_readlane -> VALU step
+ *   out[6] workgroup barrier + LDS fences, 16 waves      out[7] same, 5 waves          out[8] shader clock in MHz */
+#define QS_DIAG_LAT_N 9
+int qs_diag_latencies(qs_ctx *ctx, double out[QS_DIAG_LAT_N]);
 /* PointCloud.voxel_down_sample(voxel): mean of the points of each voxel, ascending voxel order
  * (Open3D's order is unspecified).  out_xy == NULL queries the count. */
 int qs_voxel_downsample(qs_ctx *ctx, const double *xy, size_t n, double voxel, double *out_xy,
@@ -262,7 +271,8 @@ int qs_ekf_state(qs_ctx *ctx, int32_t bot, double x[6], double P[36]);
 enum { QS_CNT_DATAGRAMS = 0, QS_CNT_ACCEPTED, QS_CNT_RAYS, QS_CNT_CELLS, QS_CNT_HITS,
        QS_CNT_CLOSURES, QS_CNT_LANDMARKS, QS_CNT_REBASES, QS_CNT_SLAM_WINDOWS, QS_CNT_SLAM_ROUNDS,
        QS_CNT_SLAM_NODE_ITERS, QS_CNT_SLAM_MISC_ITERS, QS_CNT_SLAM_CYCLES, QS_CNT_SLAM_REALTIME, QS_CNT_SLAM_CYC_A, QS_CNT_SLAM_CYC_B,
-       QS_CNT_SLAM_CYC_C, QS_CNT_EKF_WRAP_CLAMP, QS_CNT_EDGE_RAYS /* exact_trig: rays resolved on the host */, QS_CNT_N };
+       QS_CNT_SLAM_CYC_C, QS_CNT_EKF_WRAP_CLAMP, QS_CNT_EDGE_RAYS /* exact_trig: rays resolved on the host */,
+       QS_CNT_EDGE_OVERFLOW /* exact_trig: rays that found the waiting list full and were cast with the device's trig */, QS_CNT_N };
 int qs_counters(qs_ctx *ctx, uint64_t out[QS_CNT_N]);
 /* HIP-event timing of the pipeline stages on the context's stream.  enable != 0 brackets
  * each stage of every ingest with events; qs_stage_times returns accumulated ms and the
