@@ -52,8 +52,8 @@ qs_icp_nn_kernel(const double2 *__restrict__ src, size_t n_src, const double2 *_
 //     d2(i, j) = |s_i|^2 + ( |t_j|^2 - 2 s_i . t_j )  =  |s_i|^2 + [sx, sy, 1, 0] . [-2 tx, -2 ty, |t|^2, 0]^T,
 // K = 4 exactly: one v_mfma_f64_16x16x4_f64 gives the bracket S(i, j) for 16 sources x 16 targets.  The matrix value
 // is a SCREEN, never the decision: it differs from the reference expression (dx*dx + dy*dy on the raw coordinates) by
-// rounding -- coordinates are centred to keep the cancellation small -- so every result slot (source row, target
-// column class) keeps the lowest S it has seen plus a margin (2^-40 (max |s'|^2 + max |t'|^2), ~40 times the worst-case
+// rounding -- coordinates are centred to keep the cancellation small -- so every source row keeps a threshold: the lowest
+// exact squared distance it has seen, as an S, plus a margin (2^-40 (|s'|^2 + max |t'|^2), ~40 times the worst-case
 // difference between S + |s'|^2 and the reference expression); an element at or under that threshold is re-evaluated
 // with the reference expression in fp64 and competes on (d2, target index).  The true nearest target always passes
 // (its S is within the margin of every other S of its row), so the result is the scalar kernel's, bit for bit, ties
@@ -85,76 +85,106 @@ qs_icp_prep_kernel(const double2 *__restrict__ dst, size_t n_dst, size_t n_pad, 
     planes[j] = a; planes[n_pad + j] = b; planes[2 * n_pad + j] = c;
 }
 
-struct NnmState { double thr[NNM_ROWT][4], best[NNM_ROWT][4]; int best_j[NNM_ROWT][4]; };
-// what passed the screen (mk: the wave's pass mask per result slot) is re-evaluated exactly -- raw coordinates from
-// LDS -- and competes on (d2, target index)
-__device__ inline void nnm_recheck(const qs_d4 (&d)[NNM_ROWT], const unsigned long long (&mk)[NNM_ROWT][4], NnmState &st, int j,
-                                   double mrg, double tx, double ty, const double2 *s_src_lk)
+struct NnmState { double best[NNM_ROWT][4]; int best_j[NNM_ROWT][4]; };
+// The screen costs nothing but three integer ORs and one compare per row tile: the row's threshold rides in the contraction.
+// K = 4 has a free slot -- A[row][3] = -thr(row), B[3][col] = 1 -- so the MFMA delivers D = S - thr(row) and "S <= thr" is
+// the SIGN of D: the four high words of a tile's results ORed together, one v_cmp_lt_i32 (the fp64 MFMA runs on the fp64
+// vector datapath, and sixteen v_cmp_le_f64 per tile were a third of the time; 32-bit integer ops are not).  thr(row) is the
+// lowest EXACT squared distance the row has seen, minus the row's centred norm, plus the margin -- kept in LDS, lowered with
+// ds_min_f64 by whoever finds a closer target, reloaded into the A operand of the row's k = 3 lane: every column class of a
+// row tightens with every find of any of them, at once.
+// A negative D (sign bit set; a NaN with its sign set takes the path too and decides nothing) is re-evaluated exactly --
+// raw coordinates from LDS, the reference expression -- and competes on (d2, target index).
+__device__ inline void nnm_recheck(const qs_d4 (&d)[NNM_ROWT], const unsigned long long (&mk)[NNM_ROWT], NnmState &st, double (&a_op)[NNM_ROWT],
+                                   int j, double cx, double cy, double t2max, double tx, double ty, const double2 *s_src_lk,
+                                   double *s_thr_w, int lc, int lk)
 {
     #pragma unroll
-    for (int t = 0; t < NNM_ROWT; t++)
+    for (int t = 0; t < NNM_ROWT; t++) {
+        if (mk[t] == 0) continue;                                              // (uniform)
         #pragma unroll
         for (int r = 0; r < 4; r++) {
-            if (mk[t][r] == 0) continue;                                           // (uniform)
-            const double S = d[t][r];
-            if (S <= st.thr[t][r]) {
-                const double nt = S + mrg;
-                st.thr[t][r] = nt < st.thr[t][r] ? nt : st.thr[t][r];
+            if (__double_as_longlong(d[t][r]) < 0) {
                 const double2 p = s_src_lk[16 * t + 4 * r];
-                const double dx = p.x - tx, dy = p.y - ty;                         // the reference expression
+                const double dx = p.x - tx, dy = p.y - ty;                     // the reference expression
                 const double d2 = dx * dx + dy * dy;
                 if (d2 < st.best[t][r] || (d2 == st.best[t][r] && j < st.best_j[t][r])) { st.best[t][r] = d2; st.best_j[t][r] = j; }
+                const double ux = p.x - cx, uy = p.y - cy;
+                const double u2 = ux * ux + uy * uy;
+                // S = d2 - |s'|^2 up to rounding; the margin (2^-40 of the operands' scale, ~40 x that rounding) on top
+                const double nt = (d2 - u2) + (u2 + t2max) * 0x1p-40;
+                if (nt < INFINITY) __hip_atomic_fetch_min(&s_thr_w[16 * t + 4 * r + lk], nt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
+        // the wave's LDS operations complete in order: the reload below sees the minima above
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const double th = __hip_atomic_load(&s_thr_w[16 * t + lc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (lk == 3) a_op[t] = -th;
+    }
 }
-// One step: the NNM_ROWT MFMAs of the NEXT target tile (operand `bop`) are issued one by one, each followed by the
-// compares of a quarter of the CURRENT tile's products with their thresholds: 16 v_cmp_le_f64 into scalar masks and 16
-// scalar ORs are the whole screen (fp64 compares run on the units the fp64 MFMA runs on -- MI355X's fp64 matrix rate IS
-// its fp64 vector rate -- so every compare saved is matrix time).
+// One step: the NNM_ROWT MFMAs of the NEXT target tile (operand `bop`) are issued one by one, each followed by the screen of
+// one row tile of the CURRENT tile's products: is any of its four results negative?
 #define NNM_STEP(dnew, dold, bop, mk, anym)                                                                    \
     _Pragma("unroll") for (int t = 0; t < NNM_ROWT; t++) {                                                      \
         dnew[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_op[t], bop, zero, 0, 0, 0);                            \
-        _Pragma("unroll") for (int r = 0; r < 4; r++) { mk[t][r] = __ballot(dold[t][r] <= st.thr[t][r]); anym |= mk[t][r]; } \
+        const int h_ = (int)(__double_as_longlong(dold[t][0]) >> 32) | (int)(__double_as_longlong(dold[t][1]) >> 32) |   \
+                       (int)(__double_as_longlong(dold[t][2]) >> 32) | (int)(__double_as_longlong(dold[t][3]) >> 32);    \
+        mk[t] = __ballot(h_ < 0); anym |= mk[t];                                                                \
     }
 
+// Work item = (pair of 64-source groups, part of the targets): a launch is n_groups x n_parts workgroups, dealt to the CUs as
+// slots free up, so that the chip stays full whatever n_src is (one item per wave over ALL targets left 1 563 waves on 2 048
+// wave slots at 10^5 points: a quarter of the machine idle behind the SIMDs that had two).  A part starts from the thresholds
+// the parts before it left in thr_seed (HBM, one per source, lowered with a global fp64 atomic min at the end of every part:
+// workgroups are dispatched in blockIdx order -- all groups' part 0, then part 1 ... -- so a part usually starts warm; any
+// order is correct, a seed is only ever an exact distance some target really has).  Every part writes the best (d2, target)
+// it found per source; qs_icp_nn_merge_kernel takes the lexicographic minimum over the parts.
 __global__ void __launch_bounds__(NNM_WAVES * QS_WAVE)
 qs_icp_nn_mfma_kernel(const double2 *__restrict__ src, size_t n_src, const double2 *__restrict__ dst, size_t n_dst,
-                      const double *__restrict__ planes, size_t n_pad, double cx, double cy, double t2max, double max_d2,
-                      unsigned int chunk_step, int *__restrict__ corr, double *__restrict__ d2_out)
+                      const double *__restrict__ planes, size_t n_pad, double cx, double cy, double t2max,
+                      unsigned int n_groups, unsigned int chunks_per_part, double *__restrict__ thr_seed,
+                      int *__restrict__ part_j, double *__restrict__ part_d2)
 {
     __shared__ double s_b[3][NNM_CHUNK];                 // operand planes of the chunk
     __shared__ double s_tx[NNM_CHUNK], s_ty[NNM_CHUNK];  // its raw coordinates (re-evaluation)
     __shared__ double2 s_src[NNM_WAVES][16 * NNM_ROWT];  // the wave's raw source coordinates
+    __shared__ double s_thr[NNM_WAVES][16 * NNM_ROWT];   // the rows' thresholds
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lc = lane & 15, lk = lane >> 4;
-    const size_t row0 = ((size_t)blockIdx.x * NNM_WAVES + wave) * (16 * NNM_ROWT);
+    const unsigned int group = blockIdx.x % n_groups, part = blockIdx.x / n_groups;
+    const size_t row0 = ((size_t)group * NNM_WAVES + wave) * (16 * NNM_ROWT);
 
-    double a_op[NNM_ROWT];                       // A fragment: A[row = lane & 15][k = lane >> 4]
+    double a_op[NNM_ROWT];                       // A fragment: A[row = lane & 15][k = lane >> 4]; k = 3: minus the row's threshold
     NnmState st;                                 // per result slot: row = row0 + 16 t + (lane >> 4) + 4 r, column class lane & 15
-    double s2 = 0.0;
     #pragma unroll
     for (int t = 0; t < NNM_ROWT; t++) {
         const size_t ra = row0 + 16 * t + lc;
         const double2 pa = ra < n_src ? src[ra] : make_double2(cx, cy);
-        if (lk == 0) s_src[wave][16 * t + lc] = pa;
+        const double seed = ra < n_src ? __hip_atomic_load(&thr_seed[ra], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : INFINITY;
+        if (lk == 0) { s_src[wave][16 * t + lc] = pa; s_thr[wave][16 * t + lc] = seed; }
         const double ux = pa.x - cx, uy = pa.y - cy;
-        a_op[t] = lk == 0 ? ux : (lk == 1 ? uy : (lk == 2 ? 1.0 : 0.0));
-        const double u2 = ux * ux + uy * uy;
-        s2 = (u2 > s2) ? u2 : s2;                // (NaN rows: never larger; their S is NaN and never passes)
+        a_op[t] = lk == 0 ? ux : (lk == 1 ? uy : (lk == 2 ? 1.0 : -seed));
         #pragma unroll
-        for (int r = 0; r < 4; r++) { st.thr[t][r] = INFINITY; st.best[t][r] = INFINITY; st.best_j[t][r] = 0x7fffffff; }
+        for (int r = 0; r < 4; r++) { st.best[t][r] = INFINITY; st.best_j[t][r] = 0x7fffffff; }
     }
-    #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(s2, off); s2 = o > s2 ? o : s2; }
-    const double mrg = (s2 + t2max) * 0x1p-40;   // one margin for the wave's 64 rows: the largest of theirs
     const qs_d4 zero = {0.0, 0.0, 0.0, 0.0};
     const double2 *const s_src_lk = &s_src[wave][lk];
-    const int pk = lk < 3 ? lk : 0;              // lanes of k = 3 multiply by A = 0: any finite B would do; they read plane 0 ...
+    double *const s_thr_w = s_thr[wave];
+    const int pk = lk < 3 ? lk : 0;              // lanes of k = 3 carry B = 1 (the threshold's multiplier); they read plane 0 and drop it
 
-    const unsigned int n_chunks = (unsigned int)((n_pad + NNM_CHUNK - 1) / NNM_CHUNK);
+    // this part's chunks, visited in steps of ~0.618 of their number (coprime: every chunk exactly once; a map's points come
+    // in raster order: in stream order the thresholds would crawl)
+    const unsigned int n_chunks_all = (unsigned int)((n_pad + NNM_CHUNK - 1) / NNM_CHUNK);
+    const unsigned int c_lo = part * chunks_per_part;
+    const unsigned int n_chunks = c_lo < n_chunks_all ? min(chunks_per_part, n_chunks_all - c_lo) : 0u;
+    unsigned int chunk_step = (unsigned int)(0.6180339887 * n_chunks);
+    if (chunk_step < 1) chunk_step = 1;
+    for (;;) { unsigned int a = chunk_step, b = n_chunks; while (b) { const unsigned int t = a % b; a = b; b = t; } if (a <= 1) break; chunk_step++; }
     unsigned int ci = 0;
     for (unsigned int it = 0; it < n_chunks; it++, ci = (ci + chunk_step) % n_chunks) {
-        const size_t base = (size_t)ci * NNM_CHUNK;
+        const size_t base = (size_t)(c_lo + ci) * NNM_CHUNK;
         const size_t cnt = (n_pad - base < NNM_CHUNK) ? n_pad - base : NNM_CHUNK;      // a multiple of 16
         __syncthreads();
         for (size_t j = tid; j < cnt; j += NNM_WAVES * QS_WAVE) {
@@ -167,36 +197,28 @@ qs_icp_nn_mfma_kernel(const double2 *__restrict__ src, size_t n_src, const doubl
         // two accumulator sets (no copies), B operands read from LDS one step ahead of their MFMAs
         qs_d4 dA[NNM_ROWT], dB[NNM_ROWT];
         double b_cur = s_b[pk][lc];
-        b_cur = lk < 3 ? b_cur : 0.0;            // ... and turn it into the operand's zero row (-2 tx' may be inf / NaN)
+        b_cur = lk < 3 ? b_cur : 1.0;
         double b_nxt = tiles > 1 ? s_b[pk][16 + lc] : 0.0;
         #pragma unroll
         for (int t = 0; t < NNM_ROWT; t++) dA[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_op[t], b_cur, zero, 0, 0, 0);
         for (int tile = 0; tile < tiles; tile += 2) {
             // dA = tile, issue tile + 1 into dB
-            b_cur = lk < 3 ? b_nxt : 0.0;
+            b_cur = lk < 3 ? b_nxt : 1.0;
             if (tile + 2 < tiles) b_nxt = s_b[pk][16 * (tile + 2) + lc];
-            unsigned long long mk[NNM_ROWT][4], anym = 0;     // (past the last tile the MFMAs run on a stale operand; nobody looks)
+            unsigned long long mk[NNM_ROWT], anym = 0;        // (past the last tile the MFMAs run on a stale operand; nobody looks)
             const bool i1 = tile + 1 < tiles;
             NNM_STEP(dB, dA, b_cur, mk, anym)
-            if (anym) nnm_recheck(dA, mk, st, (int)(base + 16 * (size_t)tile + lc), mrg, s_tx[16 * tile + lc], s_ty[16 * tile + lc], s_src_lk);
+            if (anym) nnm_recheck(dA, mk, st, a_op, (int)(base + 16 * (size_t)tile + lc), cx, cy, t2max, s_tx[16 * tile + lc], s_ty[16 * tile + lc],
+                                  s_src_lk, s_thr_w, lc, lk);
             if (!i1) break;
             // dB = tile + 1, issue tile + 2 into dA
-            b_cur = lk < 3 ? b_nxt : 0.0;
+            b_cur = lk < 3 ? b_nxt : 1.0;
             if (tile + 3 < tiles) b_nxt = s_b[pk][16 * (tile + 3) + lc];
             anym = 0;
             NNM_STEP(dA, dB, b_cur, mk, anym)
-            if (anym) nnm_recheck(dB, mk, st, (int)(base + 16 * (size_t)(tile + 1) + lc), mrg, s_tx[16 * (tile + 1) + lc], s_ty[16 * (tile + 1) + lc], s_src_lk);
+            if (anym) nnm_recheck(dB, mk, st, a_op, (int)(base + 16 * (size_t)(tile + 1) + lc), cx, cy, t2max, s_tx[16 * (tile + 1) + lc],
+                                  s_ty[16 * (tile + 1) + lc], s_src_lk, s_thr_w, lc, lk);
         }
-        // the 16 lanes of a source row (same lane >> 4) share their lowest threshold
-        #pragma unroll
-        for (int t = 0; t < NNM_ROWT; t++)
-            #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                double v = st.thr[t][r];
-                #pragma unroll
-                for (int off = 8; off > 0; off >>= 1) { const double o = __shfl_xor(v, off); v = o < v ? o : v; }
-                st.thr[t][r] = v;
-            }
     }
     // the 16 lanes that hold one source row: lexicographic minimum of (d2, j)
     #pragma unroll
@@ -211,12 +233,40 @@ qs_icp_nn_mfma_kernel(const double2 *__restrict__ src, size_t n_src, const doubl
                 b = take ? ob : b; bj = take ? oj : bj;
             }
             const size_t rr = row0 + lk + 16 * t + 4 * r;
-            if (lc == 0 && rr < n_src) {
-                const bool ok = bj != 0x7fffffff && b < max_d2;
-                corr[rr] = ok ? bj : -1;
-                d2_out[rr] = ok ? b : 0.0;
-            }
+            if (lc == 0 && rr < n_src) { part_j[(size_t)part * n_src + rr] = bj; part_d2[(size_t)part * n_src + rr] = b; }
         }
+    // what this part learned, for the parts that start after it
+    #pragma unroll
+    for (int t = 0; t < NNM_ROWT; t++) {
+        const size_t ra = row0 + 16 * t + lc;
+        if (lk == 0 && ra < n_src) {
+            const double th = s_thr_w[16 * t + lc];
+            if (th < INFINITY) __hip_atomic_fetch_min(&thr_seed[ra], th, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// lexicographic minimum of (d2, target index) over the parts -> corr / d2 (Open3D: a correspondence only under max_dist)
+__global__ void __launch_bounds__(ICP_BLOCK)
+qs_icp_nn_merge_kernel(size_t n_src, unsigned int n_parts, const int *__restrict__ part_j, const double *__restrict__ part_d2,
+                       double max_d2, int *__restrict__ corr, double *__restrict__ d2_out)
+{
+    const size_t i = (size_t)blockIdx.x * ICP_BLOCK + threadIdx.x;
+    if (i >= n_src) return;
+    double b = INFINITY; int bj = 0x7fffffff;
+    for (unsigned int p = 0; p < n_parts; p++) {
+        const double d = part_d2[(size_t)p * n_src + i]; const int j = part_j[(size_t)p * n_src + i];
+        if (d < b || (d == b && j < bj)) { b = d; bj = j; }
+    }
+    const bool ok = bj != 0x7fffffff && b < max_d2;
+    corr[i] = ok ? bj : -1;
+    d2_out[i] = ok ? b : 0.0;
+}
+__global__ void __launch_bounds__(ICP_BLOCK)
+qs_icp_fill_inf_kernel(double *__restrict__ v, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * ICP_BLOCK + threadIdx.x;
+    if (i < n) v[i] = INFINITY;
 }
 
 // ---- fixed-order two-level sums ---------------------------------------------------------------------
@@ -326,19 +376,32 @@ hipError_t qs_launch_icp_prep(qs_ctx *c, const double2 *dst, size_t n_dst, size_
     return hipGetLastError();
 }
 
-hipError_t qs_launch_icp_nn_mfma(qs_ctx *c, const double2 *src, size_t n_src, const double2 *dst, size_t n_dst,
-                                 const double *planes, size_t n_pad, double cx, double cy, double t2max, double max_d2,
-                                 int *corr, double *d2)
+// How the targets are cut into parts: enough workgroups to keep every slot busy through the tail (>= 6 per slot of the 1 024 a
+// launch holds: 4 workgroups per CU), no part shorter than 8 chunks.
+void qs_icp_nn_plan(size_t n_src, size_t n_pad, unsigned int *n_groups, unsigned int *n_parts, unsigned int *chunks_per_part)
 {
     const size_t rows_per_wg = (size_t)NNM_WAVES * 16 * NNM_ROWT;
-    // chunk visiting order: steps of ~0.618 n_chunks, coprime with n_chunks (every chunk exactly once)
+    const unsigned int groups = (unsigned int)((n_src + rows_per_wg - 1) / rows_per_wg);
     const unsigned int n_chunks = (unsigned int)((n_pad + NNM_CHUNK - 1) / NNM_CHUNK);
-    unsigned int step = (unsigned int)(0.6180339887 * n_chunks);
-    if (step < 1) step = 1;
-    auto gcd = [](unsigned int a, unsigned int b) { while (b) { const unsigned int t = a % b; a = b; b = t; } return a; };
-    while (gcd(step, n_chunks) != 1) step++;
-    hipLaunchKernelGGL(qs_icp_nn_mfma_kernel, dim3((unsigned int)((n_src + rows_per_wg - 1) / rows_per_wg)), dim3(NNM_WAVES * QS_WAVE),
-                       0, c->stream, src, n_src, dst, n_dst, planes, n_pad, cx, cy, t2max, max_d2, step % n_chunks, corr, d2);
+    unsigned int parts = (6u * 1024u + groups - 1) / groups;
+    const unsigned int max_parts = n_chunks / 8 > 0 ? n_chunks / 8 : 1;
+    if (parts > max_parts) parts = max_parts;
+    if (parts < 1) parts = 1;
+    const unsigned int cpp = (n_chunks + parts - 1) / parts;
+    *n_groups = groups; *chunks_per_part = cpp; *n_parts = (n_chunks + cpp - 1) / cpp;
+}
+
+hipError_t qs_launch_icp_nn_mfma(qs_ctx *c, const double2 *src, size_t n_src, const double2 *dst, size_t n_dst,
+                                 const double *planes, size_t n_pad, double cx, double cy, double t2max, double max_d2,
+                                 int *corr, double *d2, int *part_j, double *part_d2, double *thr_seed)
+{
+    unsigned int groups, parts, cpp;
+    qs_icp_nn_plan(n_src, n_pad, &groups, &parts, &cpp);
+    hipLaunchKernelGGL(qs_icp_fill_inf_kernel, dim3((unsigned int)((n_src + ICP_BLOCK - 1) / ICP_BLOCK)), dim3(ICP_BLOCK), 0, c->stream, thr_seed, n_src);
+    hipLaunchKernelGGL(qs_icp_nn_mfma_kernel, dim3(groups * parts), dim3(NNM_WAVES * QS_WAVE),
+                       0, c->stream, src, n_src, dst, n_dst, planes, n_pad, cx, cy, t2max, groups, cpp, thr_seed, part_j, part_d2);
+    hipLaunchKernelGGL(qs_icp_nn_merge_kernel, dim3((unsigned int)((n_src + ICP_BLOCK - 1) / ICP_BLOCK)), dim3(ICP_BLOCK), 0, c->stream,
+                       n_src, parts, part_j, part_d2, max_d2, corr, d2);
     return hipGetLastError();
 }
 

@@ -1254,11 +1254,12 @@ extern "C" int qs_rasterise(qs_ctx *c, const double *xy, size_t n, double res, i
 // ---- ICP / voxel down-sample (map_merger.py:45-60; Open3D semantics, parity unpinned) ------------------
 // The correspondence search (nearest target of every source point) has two implementations with identical results:
 // the scalar fp64 brute force and the MFMA-screened one (icp.hip).  mode 0 = auto (MFMA from 64 targets up).
-struct NnPlan { double cx, cy, t2max; size_t n_pad; double *planes; bool mfma; };
+struct NnPlan { double cx, cy, t2max; size_t n_pad; double *planes; bool mfma; int *part_j; double *part_d2, *thr_seed; };
+static void nn_free(NnPlan &pl) { hipFree(pl.planes); hipFree(pl.part_j); hipFree(pl.part_d2); hipFree(pl.thr_seed); pl.planes = nullptr; }
 
-static hipError_t nn_prepare(qs_ctx *c, const double *dst_xy, size_t n_dst, const double2 *d_dst, int mode, NnPlan &pl)
+static hipError_t nn_prepare(qs_ctx *c, const double *dst_xy, size_t n_dst, const double2 *d_dst, int mode, NnPlan &pl, size_t n_src)
 {
-    pl = NnPlan{0, 0, 0, 0, nullptr, false};
+    pl = NnPlan{0, 0, 0, 0, nullptr, false, nullptr, nullptr, nullptr};
     pl.mfma = mode == 2 || (mode == 0 && n_dst >= 64);
     if (!pl.mfma) return hipSuccess;
     double mnx = INFINITY, mny = INFINITY, mxx = -INFINITY, mxy = -INFINITY;
@@ -1273,13 +1274,20 @@ static hipError_t nn_prepare(qs_ctx *c, const double *dst_xy, size_t n_dst, cons
     pl.n_pad = (n_dst + 15) / 16 * 16;
     hipError_t e = hipMalloc((void **)&pl.planes, 3 * pl.n_pad * sizeof(double));
     if (e == hipSuccess) e = qs_launch_icp_prep(c, d_dst, n_dst, pl.n_pad, pl.cx, pl.cy, pl.planes);
+    // per-part results and the sources' threshold seeds (the targets are cut into parts: icp.hip)
+    unsigned int groups, parts, cpp;
+    qs_icp_nn_plan(n_src, pl.n_pad, &groups, &parts, &cpp);
+    if (e == hipSuccess) e = hipMalloc((void **)&pl.part_j, (size_t)parts * n_src * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void **)&pl.part_d2, (size_t)parts * n_src * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void **)&pl.thr_seed, n_src * sizeof(double));
     return e;
 }
 
 static hipError_t nn_run(qs_ctx *c, const NnPlan &pl, const double2 *d_src, size_t n_src, const double2 *d_dst, size_t n_dst,
                          double max_d2, int *d_corr, double *d_d2)
 {
-    if (pl.mfma) return qs_launch_icp_nn_mfma(c, d_src, n_src, d_dst, n_dst, pl.planes, pl.n_pad, pl.cx, pl.cy, pl.t2max, max_d2, d_corr, d_d2);
+    if (pl.mfma) return qs_launch_icp_nn_mfma(c, d_src, n_src, d_dst, n_dst, pl.planes, pl.n_pad, pl.cx, pl.cy, pl.t2max, max_d2, d_corr, d_d2,
+                                              pl.part_j, pl.part_d2, pl.thr_seed);
     return qs_launch_icp_nn(c, d_src, n_src, d_dst, n_dst, max_d2, d_corr, d_d2);
 }
 
@@ -1304,7 +1312,7 @@ extern "C" int qs_nn_search(qs_ctx *c, const double *src_xy, size_t n_src, const
     if (e == hipSuccess) e = hipMemcpyAsync(d_src, src_xy, n_src * sizeof(double2), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_dst, dst_xy, n_dst * sizeof(double2), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipEventRecord(ev[0], c->stream);
-    if (e == hipSuccess) e = nn_prepare(c, dst_xy, n_dst, d_dst, mode, pl);
+    if (e == hipSuccess) e = nn_prepare(c, dst_xy, n_dst, d_dst, mode, pl, n_src);
     if (e == hipSuccess) e = hipEventRecord(ev[1], c->stream);
     if (e == hipSuccess) e = nn_run(c, pl, d_src, n_src, d_dst, n_dst, max_dist * max_dist, d_corr, d_d2);      // warm (code load, caches)
     if (e == hipSuccess) e = hipEventRecord(ev[2], c->stream);
@@ -1315,7 +1323,7 @@ extern "C" int qs_nn_search(qs_ctx *c, const double *src_xy, size_t n_src, const
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e == hipSuccess && ms) { hipEventElapsedTime(&ms[0], ev[2], ev[3]); hipEventElapsedTime(&ms[1], ev[0], ev[1]); }
     for (int k = 0; k < 4; k++) if (ev[k]) hipEventDestroy(ev[k]);
-    hipFree(d_src); hipFree(d_dst); hipFree(d_corr); hipFree(d_d2); hipFree(pl.planes);
+    hipFree(d_src); hipFree(d_dst); hipFree(d_corr); hipFree(d_d2); nn_free(pl);
     if (e != hipSuccess) return qs_fail(c, QS_E_HIP, "qs_nn_search", e);
     return QS_OK;
 }
@@ -1338,7 +1346,7 @@ extern "C" int qs_icp(qs_ctx *c, const double *src_xy, size_t n_src, const doubl
     if (e == hipSuccess) e = hipMemcpyAsync(d_src, src_xy, n_src * sizeof(double2), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_dst, dst_xy, n_dst * sizeof(double2), hipMemcpyHostToDevice, c->stream);
     NnPlan pl{};
-    if (e == hipSuccess) e = nn_prepare(c, dst_xy, n_dst, d_dst, 0, pl);     // the targets do not move: operands once per registration
+    if (e == hipSuccess) e = nn_prepare(c, dst_xy, n_dst, d_dst, 0, pl, n_src);     // the targets do not move: operands once per registration
     double tc = 1.0, ts = 0.0, tx = 0.0, ty = 0.0;          // accumulated transform
     double out[6] = {0};
     const double zero4[4] = {0, 0, 0, 0};
@@ -1378,7 +1386,7 @@ extern "C" int qs_icp(qs_ctx *c, const double *src_xy, size_t n_src, const doubl
         if (e == hipSuccess) e = evaluate(fit, rm);
         if (e == hipSuccess && fabs(bfit - fit) < rel_fitness && fabs(brm - rm) < rel_rmse) { it++; break; }
     }
-    hipFree(d_src); hipFree(d_dst); hipFree(d_corr); hipFree(d_d2); hipFree(d_part); hipFree(d_out); hipFree(pl.planes);
+    hipFree(d_src); hipFree(d_dst); hipFree(d_corr); hipFree(d_d2); hipFree(d_part); hipFree(d_out); nn_free(pl);
     if (e != hipSuccess) return qs_fail(c, QS_E_HIP, "qs_icp", e);
     T[0] = tc; T[1] = -ts; T[2] = tx; T[3] = ts; T[4] = tc; T[5] = ty; T[6] = 0; T[7] = 0; T[8] = 1;
     *fitness = fit; *rmse = rm;

@@ -270,9 +270,10 @@ hipError_t qs_launch_icp_nn(qs_ctx *c, const double2 *src, size_t n_src, const d
                             double max_d2, int *corr, double *d2);
 hipError_t qs_launch_mfma_f64_rate(qs_ctx *c, int blocks, int iters, double *sink);
 hipError_t qs_launch_icp_prep(qs_ctx *c, const double2 *dst, size_t n_dst, size_t n_pad, double cx, double cy, double *planes);
+void qs_icp_nn_plan(size_t n_src, size_t n_pad, unsigned int *n_groups, unsigned int *n_parts, unsigned int *chunks_per_part);
 hipError_t qs_launch_icp_nn_mfma(qs_ctx *c, const double2 *src, size_t n_src, const double2 *dst, size_t n_dst,
                                  const double *planes, size_t n_pad, double cx, double cy, double t2max, double max_d2,
-                                 int *corr, double *d2);
+                                 int *corr, double *d2, int *part_j, double *part_d2, double *thr_seed);
 hipError_t qs_launch_icp_sums(qs_ctx *c, const double2 *src, size_t n_src, const double2 *dst, const int *corr,
                               const double *d2, int pass, const double means[4], double *partial, double *out6);
 hipError_t qs_launch_icp_transform(qs_ctx *c, double2 *pts, size_t n, double cs, double sn, double tx, double ty);

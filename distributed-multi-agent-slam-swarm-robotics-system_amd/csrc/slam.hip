@@ -147,6 +147,16 @@ qs_slam_index_kernel(size_t n, QsBatch b, QsSlamBatch sb, const QsGraphDev *__re
     }
 }
 
+#ifdef QS_CHAIN_PROF3
+#define CH_TRACE_WINDOWS 16384
+__device__ unsigned long long g_chain_trace[CH_TRACE_WINDOWS * 16];
+extern "C" int qs_debug_chain_trace(unsigned long long *out, size_t n_windows)
+{
+    if (n_windows > CH_TRACE_WINDOWS) n_windows = CH_TRACE_WINDOWS;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_chain_trace), n_windows * 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : -2;
+}
+#endif
+
 // ---- the chain: one workgroup (CH_WAVES waves) per pose graph ------------------------------------
 // The graph's landmark events are walked in windows of < MIN_POSES_BETWEEN nodes: a query never sees a
 // landmark of its own window (:300), and an agent closes at most once per window (:304), so the
@@ -502,8 +512,12 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
 #define CH_R2 (ring == 2 ? 0 : ring + 1)       // slot of window V - 2
 // what every role does at the end of a phase
 #ifdef QS_CHAIN_PROF3
-#define CH_P3_DECL unsigned long long p3_busy = 0, p3_t = __builtin_amdgcn_s_memtime()
-#define CH_PHASE_END(active_, k_)  p3_busy += __builtin_amdgcn_s_memtime() - p3_t; lds_barrier(); p3_t = __builtin_amdgcn_s_memtime(); e += (k_); have_prev = (active_); if (active_) { par ^= 1; ring = ring == 2 ? 0 : ring + 1; }
+// per-window busy time of every role of graph 0 (first CH_TRACE_WINDOWS phases): [phase][wave] cycles from the barrier to the
+// role's arrival at the next one; tools/chain_trace.py reads it through qs_debug_chain_trace
+#define CH_P3_DECL unsigned long long p3_busy = 0, p3_t = __builtin_amdgcn_s_memtime(); unsigned int p3_w = 0
+#define CH_PHASE_END(active_, k_)  { const unsigned long long p3_d = __builtin_amdgcn_s_memtime() - p3_t; p3_busy += p3_d; \
+    if (g == 0 && lane == 0 && p3_w < CH_TRACE_WINDOWS) g_chain_trace[p3_w * 16 + wave] = p3_d; p3_w++; } \
+    lds_barrier(); p3_t = __builtin_amdgcn_s_memtime(); e += (k_); have_prev = (active_); if (active_) { par ^= 1; ring = ring == 2 ? 0 : ring + 1; }
 #define CH_P3_REPORT(slot_) if (lane == 0) atomicAdd(&counters[slot_], p3_busy)
 #else
 #define CH_P3_DECL

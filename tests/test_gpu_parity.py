@@ -1034,12 +1034,17 @@ def test_nn_search_mfma_equals_scalar_equals_numpy(pkg):
     cases.append(("nothing in range", rng.uniform(0, 1, (100, 2)), rng.uniform(50, 51, (130, 2)), 1.0))
     bad = rng.uniform(-5, 5, (200, 2)); bad[7] = np.nan; bad[9, 0] = np.inf
     cases.append(("non-finite targets", rng.uniform(-5, 5, (150, 2)), bad, 2.0))
+    # sources that are non-finite or far outliers (the screen's margin is per row: one of them among a wave's 64 rows
+    # must neither change its neighbours' results nor their speed), and enough of both for several target parts
+    sb = rng.uniform(-5, 5, (300, 2)); sb[3] = np.nan; sb[70, 1] = np.inf; sb[130] = (1.0e9, -3.0e8); sb[131] = (-1.0e150, 2.0)
+    cases.append(("non-finite and outlier sources", sb, rng.uniform(-5, 5, (900, 2)), 2.0))
+    cases.append(("many parts", rng.uniform(-30, 30, (700, 2)), rng.uniform(-30, 30, (40000, 2)), 3.0))
     with pkg.QuasarMapper(64, 0.05, -1.6, -1.6) as m:
         for name, src, dst, md in cases:
             c1, d1, _ = m.nn_search(src, dst, md, 1)
             c2, d2, _ = m.nn_search(src, dst, md, 2)
             assert (c1 == c2).all() and (d1 == d2).all(), name
-            if not np.isfinite(dst).all():
+            if not (np.isfinite(dst).all() and np.isfinite(src).all()):
                 continue
             cr, dr = ref(src, dst, md)
             assert (c1 == cr).all() and (d1 == dr).all(), name
