@@ -3,6 +3,7 @@
 #include <math.h>
 #include <algorithm>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "qs_internal.h"
@@ -571,7 +572,29 @@ static int ingest_device(qs_ctx *c, const uint8_t *d_pkts, size_t n, size_t stri
     if (c->cfg.enable_ekf) {
         // fork: the filter only needs the decoded fields, never the map (and the map never the filter)
         if (!c->ekf_stream) {
-            HIPCHK(c, hipStreamCreateWithFlags(&c->ekf_stream, hipStreamNonBlocking));
+            // The filter's stream keeps off the lowest 32 CUs.  Its kernels run beside the loop-closure chain, whose workgroups
+            // (one per pose graph, each a whole CU's worth of latency-bound waves) lose ~10 % when scan kernels share their
+            // SIMDs; with 32 CUs left alone the dispatcher puts the chain there (64 bots / 32 graphs: chain 1.26 -> 1.15 ms,
+            // step 1.89 -> 1.80 ms; tools/ekf_cu_mask_probe.sh).  QS_EKF_CU_MASK = hex words (lowest CUs first) overrides,
+            // "none" switches the mask off; a device too small for it, or a refusal, falls back to an ordinary stream.
+            const char *mk = getenv("QS_EKF_CU_MASK");
+            std::vector<uint32_t> words;
+            if (mk && *mk && strcmp(mk, "none") != 0) {
+                char *end = nullptr;
+                for (const char *q = mk; *q;) { words.push_back((uint32_t)strtoul(q, &end, 16)); if (end == q) break; q = (*end == ',') ? end + 1 : end; }
+            } else if (!mk || !*mk) {
+                hipDeviceProp_t prop;
+                if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount >= 128) {
+                    words.assign((size_t)(prop.multiProcessorCount + 31) / 32, 0xffffffffu);
+                    words[0] = 0u;
+                }
+            }
+            if (!words.empty() && hipExtStreamCreateWithCUMask(&c->ekf_stream, (uint32_t)words.size(), words.data()) != hipSuccess) {
+                (void)hipGetLastError();
+                c->ekf_stream = nullptr;
+            }
+            if (!c->ekf_stream)
+                HIPCHK(c, hipStreamCreateWithFlags(&c->ekf_stream, hipStreamNonBlocking));
             HIPCHK(c, hipEventCreateWithFlags(&c->ev_decoded, hipEventDisableTiming));
             HIPCHK(c, hipEventCreateWithFlags(&c->ev_ekf_done, hipEventDisableTiming));
         }
