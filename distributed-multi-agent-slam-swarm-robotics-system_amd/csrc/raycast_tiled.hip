@@ -285,6 +285,64 @@ qs_scatter_kernel(size_t n, QsBatch b, QtWorkspace ws, int size, unsigned long l
     }
 }
 
+// ---- experiment (off in production: -DQT_CLIP=1 builds it, tools/ab_raster_clip.sh measures it) ----------
+// Clip a record's walk to its tile in closed form: the walk of dual_bot_mapper.py:166-178 in major / minor form has, after t
+// steps, minor offset m(t) = (2 t dmin + dmaj - 1) div (2 dmaj) and error term E(t) = dmaj - dmin + m(t) dmaj - t dmin
+// (oracle-checked for every |d| <= 40; the in-tile steps are one interval [ta, tb] because both coordinates are monotone).
+#ifndef QT_CLIP
+#define QT_CLIP 0
+#endif
+__device__ inline int qt_idiv(int n, int d) { return __float2int_rz(__fdividef((float)n + 0.5f, (float)d)); }   // exact: 0 <= n < 2^14, 0 < d < 2^8
+__device__ inline int qt_cdiv(int a, int b) { return qt_idiv(a + b - 1, b); }
+// first in-tile step ta and the number of in-tile FREE cells of the walk (x, y) -> (x1, y1) in a tile of tw x th cells
+__device__ inline int qt_clip_span(int x, int y, int x1, int y1, int tw, int th, int &ta)
+{
+    const int dx = abs(x1 - x), dy = abs(y1 - y), sx = x < x1 ? 1 : -1, sy = y < y1 ? 1 : -1;
+    const bool xmaj = dx >= dy;
+    const int dmaj = xmaj ? dx : dy, dmin = xmaj ? dy : dx;
+    const int cm0 = xmaj ? x : y, sm = xmaj ? sx : sy, Wm = xmaj ? tw : th;
+    const int cn0 = xmaj ? y : x, sn = xmaj ? sy : sx, Wn = xmaj ? th : tw;
+    int a = 0, b = dmaj - 1;
+    if (sm > 0) { a = max(a, -cm0); b = min(b, Wm - 1 - cm0); } else { a = max(a, cm0 - (Wm - 1)); b = min(b, cm0); }
+    const int lo = sn > 0 ? max(0, -cn0) : max(0, cn0 - (Wn - 1)), hi = sn > 0 ? Wn - 1 - cn0 : cn0;
+    if (hi < 0) b = -1;
+    else if (dmin == 0) { if (lo > 0) b = -1; }
+    else {
+        if (lo > 0) a = max(a, qt_cdiv(2 * dmaj * lo - dmaj + 1, 2 * dmin));
+        b = min(b, qt_cdiv(2 * dmaj * (hi + 1) - dmaj + 1, 2 * dmin) - 1);
+    }
+    ta = a;
+    return max(0, b - a + 1);
+}
+#if QT_CLIP
+// experiment only: the records of every tile re-ordered by clipped span (ascending), so that the 64 records a wave walks
+// together have walks of similar length -- what a regrouping scatter pass would deliver, without its cost
+__global__ void __launch_bounds__(256)
+qs_clip_sort_kernel(QtWorkspace ws, int size, uint2 *__restrict__ tmp)
+{
+    __shared__ unsigned int s_bin[66];
+    const int tile = blockIdx.x, tid = threadIdx.x;
+    const unsigned int n = ws.tile_count[tile], base = ws.tile_base[tile];
+    if (n == 0) return;
+    const int tx0 = (tile % ws.tiles_x) << QT_TILE_SHIFT, ty0 = (tile / ws.tiles_x) << QT_TILE_SHIFT;
+    const int tw = min(QT_TILE, size - tx0), th = min(QT_TILE, size - ty0);
+    for (int t = tid; t < 66; t += 256) s_bin[t] = 0;
+    __syncthreads();
+    auto span_of = [&](uint2 rec) {
+        const int x = (signed char)(rec.x & 0xffu), y = (signed char)((rec.x >> 8) & 0xffu);
+        const int x1 = (signed char)((rec.x >> 16) & 0xffu), y1 = (signed char)(rec.x >> 24);
+        int ta; return qt_clip_span(x, y, x1, y1, tw, th, ta);
+    };
+    for (unsigned int j = tid; j < n; j += 256) atomicAdd(&s_bin[span_of(ws.recs[base + j]) + 1], 1u);
+    __syncthreads();
+    if (tid == 0) for (int t = 1; t < 66; t++) s_bin[t] += s_bin[t - 1];
+    __syncthreads();
+    for (unsigned int j = tid; j < n; j += 256) { const uint2 r = ws.recs[base + j]; tmp[base + atomicAdd(&s_bin[span_of(r)], 1u)] = r; }
+    __syncthreads();
+    for (unsigned int j = tid; j < n; j += 256) ws.recs[base + j] = tmp[base + j];
+}
+#endif
+
 // ---- pass D: LDS raster + merge -------------------------------------------------------------------
 // Persistent workgroups: workgroup w takes the contiguous run of work items [w * per, (w + 1) * per).
 // Items are in tile order, so consecutive items mostly belong to the same tile (two robots in one
@@ -397,7 +455,11 @@ qs_raster_kernel(QtWorkspace ws, int size, unsigned int *__restrict__ stamps,
     // addresses.  Each wave therefore takes 8 groups of 8 consecutive records (two packets: 8
     // different rays), the groups QT_BLOCK / 8 records apart.
     const int lane = tid & (QS_WAVE - 1), wave = tid >> 6;
+#if QT_CLIP
+    const unsigned int slot = (unsigned int)tid;       // (experiment: records come sorted by clipped span -- neighbours walk alike in LENGTH, not in place)
+#else
     const unsigned int slot = (unsigned int)((lane >> 3) * (QT_BLOCK / 8) + wave * 8 + (lane & 7));
+#endif
     const int scratch4 = 4 * (QT_LDS_CELLS + lane);     // byte offset of this lane's scratch cell
     unsigned int wave_cells = 0;                        // wave-uniform count of cell writes (!COUNTS)
     int cur_tile = -1, since_flush = 0;
@@ -452,6 +514,16 @@ qs_raster_kernel(QtWorkspace ws, int size, unsigned int *__restrict__ stamps,
                 k = dmaj; E = dmaj - dmin; H = (dmaj + 1) >> 1; incA = dmaj - dmin; incB = -dmin;
                 sx_c = sx4; sx_n = xmaj ? sx4 : 0; sy_c = sy; sy_n = xmaj ? 0 : sy;
                 x4 = x << 2; ya = y * (4 * QT_PITCH);
+#if QT_CLIP
+                {   // start at the first in-tile step, walk the in-tile steps only
+                    int ta;
+                    k = qt_clip_span(x, y, x1, y1, tw, th, ta);
+                    const int mn = dmaj ? qt_idiv(2 * ta * dmin + dmaj - 1, 2 * dmaj) : 0;
+                    E = dmaj - dmin + mn * dmaj - ta * dmin;
+                    const int ax = xmaj ? ta : mn, ay = xmaj ? mn : ta;          // steps taken along x / y
+                    x4 += ax * sx4; ya += ay * sy;
+                }
+#endif
                 wl = (rec.y & 1u) && (unsigned int)x1 < (unsigned int)tw && (unsigned int)y1 < (unsigned int)th;
                 if (wl) {                                                      // :148-150 occupied end cell
                     const int c = y1 * QT_PITCH + x1;
@@ -461,7 +533,11 @@ qs_raster_kernel(QtWorkspace ws, int size, unsigned int *__restrict__ stamps,
             }
             if (!COUNTS) wave_cells += (unsigned int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(wl));
             for (int it = 0; __any(it < k); it++) {                            // :152-156 free cells
+#if QT_CLIP
+                const bool w = it < k;                                          // (every remaining step is inside the tile)
+#else
                 const bool w = it < k && (unsigned int)x4 < tw4 && (unsigned int)ya < tha;
+#endif
                 const int a = w ? ya + x4 : scratch4;
                 atomicMax((unsigned int *)((char *)s_stamp + a), key_free);
                 if (COUNTS) atomicAdd((unsigned int *)((char *)s_cnt + a), 1u);
@@ -566,6 +642,16 @@ hipError_t qs_launch_raycast_tiled(qs_ctx *c, size_t n, uint64_t seq0)
     // knob, and how the tests reach the long-run paths (tile changes inside a run, the 31-item flush)
     static const int env_wgs = [] { const char *e = getenv("QS_RASTER_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : QT_RASTER_WGS; }();
     const unsigned int raster_wgs = (unsigned int)(max_items < (size_t)env_wgs ? max_items : (size_t)env_wgs);
+#if QT_CLIP
+    {   // experiment: regroup by clipped span, untimed (what a regrouping scatter would deliver)
+        static const bool do_sort = [] { const char *e = getenv("QS_RASTER_SORT"); return !e || atoi(e) != 0; }();
+        static uint2 *d_tmp = nullptr; static size_t tmp_cap = 0;
+        if (do_sort) {
+            if (tmp_cap < 16 * c->cap_batch) { hipStreamSynchronize(c->stream); hipFree(d_tmp); hipMalloc((void **)&d_tmp, 16 * c->cap_batch * sizeof(uint2)); tmp_cap = 16 * c->cap_batch; }
+            hipLaunchKernelGGL(qs_clip_sort_kernel, dim3(ws.n_tiles), dim3(256), 0, c->stream, ws, c->cfg.size, d_tmp);
+        }
+    }
+#endif
     StageTimer t_raster(c, QS_STAGE_RC_RASTER);
     if (c->cfg.enable_counts)
         hipLaunchKernelGGL(qs_raster_kernel<true>, dim3(raster_wgs), dim3(QT_BLOCK), 0, c->stream, ws,
