@@ -46,6 +46,7 @@ PKG = "distributed-multi-agent-slam-swarm-robotics-system_amd"
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 HBM_COPY_GBS = 6290.0       # achievable float4-copy rate, same guide
 N_CU = 256
+PROFILE_ROUND = "r03"       # profiles/<round>/: the committed rocprofv3 summaries the replayed counter figures come from
 
 
 def parse(argv=None):
@@ -79,6 +80,8 @@ def parse(argv=None):
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="every rank uses cuda:0 (with --backend gloo): rehearses the N > 1 code path on a one-GPU box; "
                          "the numbers mean nothing")
+    ap.add_argument("--selftest-fail-rank", type=int, default=-1,
+                    help="with --spawn-selftest: this rank exits with code 3 before the rendezvous (the launcher must stop its siblings)")
     ap.add_argument("--spawn-selftest", action="store_true",
                     help="no GPU: the ranks only rendezvous (backend as given), all-reduce one number and rank 0 prints "
                          "{n_gpus: world}; used by the CPU test of the launcher")
@@ -301,7 +304,10 @@ def micro_benches(pkg, torch, dev, m, grid):
     view = torch.empty(cells, dtype=torch.int8, device=dev)
     s = timed(lambda: m.grid_i8_device(view.data_ptr()), 20)
     out["k2_view_i8"] = {"bytes": 5 * cells, "ms": s * 1e3, "gbs": 5 * cells / s / 1e9, "frac_of_peak": 5 * cells / s / 1e9 / HBM_PEAK_GBS,
-                         "frac_of_copy": 5 * cells / s / 1e9 / HBM_COPY_GBS, "rule": "size^2 x (4 B stamp read + 1 B int8 written)"}
+                         "frac_of_copy": 5 * cells / s / 1e9 / HBM_COPY_GBS, "rule": "size^2 x (4 B stamp read + 1 B int8 written)",
+                         "residency": ("Infinity-Cache resident: the stamp grid (%d MiB) is re-read from the 256 MB MALL on every repetition, so this "
+                                       "is a cache rate, not an HBM rate" % (cells * 4 >> 20)) if cells * 4 <= (128 << 20) else
+                                      "past the 256 MB Infinity Cache with its output: an HBM rate"}
     del view
     for G in (8, 64):
         st = [torch.randint(0, 1 << 30, (cells,), dtype=torch.int32, device=dev) for _ in range(G)]
@@ -399,8 +405,9 @@ def replayed_traffic(profile_dir, kernels):
     doubled per the gfx950 note of MI355X_MICROARCH.md section HBM, WRITE_SIZE as is; both in KiB).  NOT measured in
     this run: labelled as replayed wherever it is printed."""
     total, found = 0.0, False
+    rnd = PROFILE_ROUND if os.path.isdir(os.path.join(ROOT, "profiles", PROFILE_ROUND, profile_dir)) else "r02"
     for fname, scale in (("pmc_FETCH_SIZE.csv", 2.0), ("pmc_WRITE_SIZE.csv", 1.0)):
-        path = os.path.join(ROOT, "profiles", "r02", profile_dir, fname)
+        path = os.path.join(ROOT, "profiles", rnd, profile_dir, fname)
         if not os.path.exists(path):
             return None
         import csv
@@ -408,7 +415,7 @@ def replayed_traffic(profile_dir, kernels):
             if any(k in row["kernel"] for k in kernels):
                 total += float(row["avg_KiB_per_dispatch"]) * 1024.0 * scale
                 found = True
-    return total if found else None
+    return (total, rnd) if found else None
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -416,6 +423,8 @@ def selftest_rank(args):
     import torch
     import torch.distributed as dist
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if rank == args.selftest_fail_rank:
+        return 3
     dist.init_process_group(args.backend, rank=rank, world_size=world)
     t = torch.tensor([float(rank + 1)])
     dist.all_reduce(t)
@@ -547,7 +556,8 @@ def run_rank(args):
     chain_ms, ray_ms = st_ms.get("slam_chain", 0.0), st_ms.get("raycast", 0.0)
     ray_alg_gbs = alg_bytes / (ray_ms * 1e-3) / 1e9 if ray_ms > 0 else 0.0
     prof_dir = {"c1": "c1_4096", "adv": "adv_4096", "c3": "c3_4096"}[wl] if G == 4096 else f"{wl}_{G}"
-    ray_traffic = replayed_traffic(prof_dir, ("qs_rays_kernel", "qs_table_scan_kernel", "qs_scatter_kernel", "qs_raster_kernel"))
+    _rt = replayed_traffic(prof_dir, ("qs_rays_kernel", "qs_table_scan_kernel", "qs_scatter_kernel", "qs_raster_kernel"))
+    ray_traffic, prof_round = _rt if _rt else (None, PROFILE_ROUND)
     raycast_entry = {
         "kernel": "K1 raycast stage: qs_rays + qs_table_scan + qs_scatter + qs_raster", "bound": "hbm",
         "avg_launch_ms": ray_ms, "kernels_ms": {k: st_ms.get(k) for k in ("rc_rays", "rc_sort", "rc_raster")},
@@ -555,7 +565,7 @@ def run_rank(args):
         "counter_bytes_per_launch": ray_traffic,
         "counter_gbs": (ray_traffic / (ray_ms * 1e-3) / 1e9) if (ray_traffic and ray_ms > 0) else None,
         "frac_counter": (ray_traffic / (ray_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (ray_traffic and ray_ms > 0) else None,
-        "counter_source": f"replayed from profiles/r02/{prof_dir}/pmc_*.csv (rocprofv3 --pmc passes of this command), NOT measured in this run"
+        "counter_source": f"replayed from profiles/{prof_round}/{prof_dir}/pmc_*.csv (rocprofv3 --pmc passes of this command), NOT measured in this run"
                           if ray_traffic else None}
     if chain_ms >= ray_ms:
         dom_ms = chain_ms
@@ -652,7 +662,9 @@ def run_rank(args):
         if world > 1:
             # The N = 1 default is configs[1] (2 bots); this line is configs[3] (64 bots per GPU).  For a scaling figure on ONE
             # workload, the same 64-bot workload at N = 1 -- replayed from the committed run, not measured now.
-            ref = os.path.join(ROOT, "profiles", "r02", f"bench_{wl}{'' if G == 4096 else '_' + str(G)}.json")
+            ref = os.path.join(ROOT, "profiles", PROFILE_ROUND, f"bench_{wl}{'' if G == 4096 else '_' + str(G)}.json")
+            if not os.path.exists(ref):
+                ref = os.path.join(ROOT, "profiles", "r02", f"bench_{wl}{'' if G == 4096 else '_' + str(G)}.json")
             try:
                 r1 = json.load(open(ref))
                 out["same_workload_n1"] = {"value": r1["value"], "ms_per_step": r1["ms_per_step"],
@@ -663,8 +675,8 @@ def run_rank(args):
             out["roofline_streaming"] = micro
             out["copy_peak_measured_gbs"] = copy_gbs
         if world == 1 and wl == "c1" and micro is not None and not args.no_cpu_baseline:
-            out["configs2_64_bots"] = secondary_64_bots(pkg, replay, torch, dev, side, args, G, counts, bpg=2)
-            out["configs2_64_bots_one_graph"] = secondary_64_bots(pkg, replay, torch, dev, side, args, G, counts, bpg=0, steps=3, warm=1)
+            out["configs2_64_bots"] = secondary_64_bots(pkg, replay, torch, dev, side, args, G, counts, bpg=2, steps=20, warm=3)
+            out["configs2_64_bots_one_graph"] = secondary_64_bots(pkg, replay, torch, dev, side, args, G, counts, bpg=0, steps=5, warm=1)
             if out["configs2_64_bots"]["parity_checked"] is False or out["configs2_64_bots_one_graph"]["parity_checked"] is False:
                 parity = False
         if cpu is not None:

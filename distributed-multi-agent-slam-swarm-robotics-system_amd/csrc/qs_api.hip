@@ -283,7 +283,7 @@ extern "C" int qs_destroy(qs_ctx *c)
     hipFree(c->d_dirty); hipFree(c->d_counts_sent); hipFree(c->d_sf_bitmaps); hipFree(c->d_sf_lists); hipFree(c->d_sf_counts); hipFree(c->d_sf_payload);
     for (auto &p : c->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (auto e : c->ev_pool) hipEventDestroy(e);
-    if (c->ekf_stream) { hipStreamSynchronize(c->ekf_stream); hipStreamDestroy(c->ekf_stream); }
+    if (c->ekf_stream) { hipStreamSynchronize(c->ekf_stream); if (!c->ekf_stream_shared) hipStreamDestroy(c->ekf_stream); }
     if (c->ev_decoded) hipEventDestroy(c->ev_decoded);
     if (c->ev_ekf_done) hipEventDestroy(c->ev_ekf_done);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
@@ -589,9 +589,18 @@ static int ingest_device(qs_ctx *c, const uint8_t *d_pkts, size_t n, size_t stri
                     words[0] = 0u;
                 }
             }
-            if (!words.empty() && hipExtStreamCreateWithCUMask(&c->ekf_stream, (uint32_t)words.size(), words.data()) != hipSuccess) {
-                (void)hipGetLastError();
-                c->ekf_stream = nullptr;
+            // ONE masked stream per device, shared by its contexts and never destroyed: a second CU-masked queue on the same GPU
+            // slows every kernel of the process by 30-50 % (measured: two contexts, each with its own masked stream, 1.81 ->
+            // 2.79 ms per 64-bot step; tools/secondary_probe.py).  Contexts of one process then run their filters one after
+            // the other, which is how they are driven anyway (a caller serialises the calls on a context).
+            static hipStream_t g_masked[64] = {};
+            if (!words.empty() && c->device < 64) {
+                if (!g_masked[c->device] && hipExtStreamCreateWithCUMask(&g_masked[c->device], (uint32_t)words.size(), words.data()) != hipSuccess) {
+                    (void)hipGetLastError();
+                    g_masked[c->device] = nullptr;
+                }
+                c->ekf_stream = g_masked[c->device];
+                c->ekf_stream_shared = c->ekf_stream != nullptr;
             }
             if (!c->ekf_stream)
                 HIPCHK(c, hipStreamCreateWithFlags(&c->ekf_stream, hipStreamNonBlocking));

@@ -123,6 +123,7 @@ struct qs_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    bool ekf_stream_shared = false;              // the device's one CU-masked stream (qs_api.hip): not this context's to destroy
     hipStream_t ekf_stream = nullptr;            // the EKF is independent of the map: own stream,
     hipEvent_t ev_decoded = nullptr, ev_ekf_done = nullptr;   // forked after decode, joined at the end
     std::string err;

@@ -195,6 +195,19 @@ def test_bench_launcher_spawns_the_ranks_itself():
     assert rec["n_gpus"] == 2 and rec["sum"] == 3.0
 
 
+def test_bench_launcher_stops_the_siblings_of_a_rank_that_dies():
+    """a rank that exits non-zero while the others sit in a collective (here: in the rendezvous) must not leave the
+    parent waiting for them -- it terminates them and returns the failing rank's code."""
+    import subprocess
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--spawn-selftest", "--backend", "gloo",
+                          "--selftest-fail-rank", "1"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert out.returncode == 3, (out.returncode, out.stderr[-1500:])
+    assert "stopped the remaining ranks" in out.stderr and time.time() - t0 < 120
+
+
 def test_bench_refuses_a_gpus_flag_that_contradicts_the_launcher():
     """Under torchrun (RANK / WORLD_SIZE set) bench.py is ONE rank; `--gpus` must then equal the world size (round 1 parsed
     the flag and ignored it: `--gpus 8` printed n_gpus: 1)."""

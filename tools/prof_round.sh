@@ -1,12 +1,12 @@
 #!/bin/bash
 # rocprofv3 evidence for one bench.py configuration (run on the GPU box from the repo root):
-#   tools/prof_r02.sh <tag> <bench.py args...>
-#   -> gpurun_out/r02/<tag>/{bench.json, kernel_stats.csv, pmc_FETCH_SIZE.csv, pmc_WRITE_SIZE.csv}
+#   tools/prof_round.sh <tag> <bench.py args...>      (QS_PROF_ROUND=r03 by default)
+#   -> gpurun_out/${QS_PROF_ROUND:-r03}/<tag>/{bench.json, kernel_stats.csv, pmc_FETCH_SIZE.csv, pmc_WRITE_SIZE.csv}
 # kernel trace + stats in one run; FETCH_SIZE and WRITE_SIZE each in their own --pmc run (no tracing beside counters).
 set -e
 TAG=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-OUT=gpurun_out/r02/$TAG
+OUT=gpurun_out/${QS_PROF_ROUND:-r03}/$TAG
 rm -rf $OUT && mkdir -p $OUT
 ARGS="--steps 5 --warmup 2 --no-cpu-baseline --no-micro $@"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py $ARGS > $OUT/bench_under_trace.json 2> $OUT/trace.err
