@@ -221,6 +221,22 @@ def cpu_baselines(stream, grid, sample, ekf, bots, bpg, wl):
                             "sample": f"{P} independent oracle processes (capped at the box's 16-core share), each {n} packets, {dtp:.2f} s"}
     except Exception as e:                         # a baseline must never take the bench down
         out["all_cores"] = {"value": None, "error": repr(e)}
+    # the same port with a spatial index over the landmarks in place of the reference's list scan (identical closures:
+    # tests/test_oracle_golden.py): what the GPU buys over a CPU that is given the GPU path's data structure
+    try:
+        mi = oracle_for(orc, grid, bots, bpg, ekf, wl)
+        mi.use_index(True)
+        t0 = time.perf_counter()
+        mi.feed_stream(stream[:n], None, times[:n])
+        dti = time.perf_counter() - t0
+        same = all((mi.closures(g)[0] == m.closures(g)[0]).all() for g in range(m.n_graphs)) and bool((mi.grid == m.grid).all())
+        out["indexed"] = {"value": n / dti, "unit": "packets/s", "cores": 1, "kind": "port",
+                          "sample": f"the same {n} packets, oracle/oracle.c with its optional bucket index over the landmarks instead of the "
+                                    f"reference's O(landmarks) list scan, {dti:.2f} s; NOT the reference's algorithm, the same results "
+                                    f"(closures and grid identical to the list scan: {same})"}
+        del mi
+    except Exception as e:
+        out["indexed"] = {"value": None, "error": repr(e)}
     # the single-process Python statement of the reference's loop (2-bot wire only: agent in {1, 2})
     if bots == 2 and bpg in (0, 2):
         from oracle.pymapper import PyMapper

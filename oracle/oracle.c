@@ -39,10 +39,19 @@ static const double SENSOR_ANGLES_RAD[4] = {
 typedef struct { double x, y; int type; long idx; } landmark_t;
 typedef struct { long lm_idx, node_idx; double dx, dy; } closure_t;
 
+/* Optional spatial index over self.landmarks (qso_use_index): NOT the reference's algorithm -- the reference scans the whole
+ * list (:294) -- but the same answer: cells of edge >= CLOSURE_RADIUS per landmark type, each cell's landmarks in insertion
+ * order; the first match in list order is the lowest list index among the first matches of the 3 x 3 cells around the query.
+ * It exists so that the CPU baseline can also be quoted with the data structure the GPU path uses (bench.py: cpu_baseline.indexed):
+ * what the hardware buys, separated from what the index buys. */
+typedef struct { long long key; int *it; int n, cap; int used; } lmcell_t;
+typedef struct { lmcell_t *tab; size_t cap, used; } lmindex_t;
+
 typedef struct {
     long n_nodes;                 /* len(self.nodes)            :268 */
     landmark_t *lms; long n_lms, cap_lms;   /* self.landmarks   :269 */
     closure_t *cls; long n_cls, cap_cls;    /* self.closures    :270 */
+    lmindex_t ix;
 } graph_t;
 
 typedef struct {
@@ -75,6 +84,7 @@ typedef struct {
     /* build extension (qs_config.shard_bots): this mapper is one shard of a deployment that keeps ONE pose graph over
      * all bots: it runs add_pose for every packet but casts rays / keeps zones / runs the EKF for agents own_lo..own_hi */
     int own_lo, own_hi;
+    int use_index;                          /* closure search through the spatial index instead of the list scan (same result) */
 } mapper_t;
 
 /* ---- OccupancyGrid ---------------------------------------------------------------- */
@@ -117,11 +127,75 @@ static void update_ray(mapper_t *m, double rx, double ry, double hx, double hy, 
     }
 }
 
+/* ---- the optional index (see lmindex_t) ---------------------------------------------------------------------------- */
+static long long ix_key(int type, long cx, long cy) { return ((long long)type << 56) ^ ((long long)(cx & 0xfffffff) << 28) ^ (long long)(cy & 0xfffffff); }
+static long ix_coord(double v, double cell) { return (long)floor(v / cell); }
+static lmcell_t *ix_find(lmindex_t *ix, long long key, int create)
+{
+    if (ix->cap == 0) { if (!create) return NULL; ix->cap = 1024; ix->tab = calloc(ix->cap, sizeof(lmcell_t)); }
+    if (create && 2 * (ix->used + 1) > ix->cap) {           /* grow and rehash */
+        lmindex_t nx = {calloc(2 * ix->cap, sizeof(lmcell_t)), 2 * ix->cap, 0};
+        for (size_t i = 0; i < ix->cap; i++) if (ix->tab[i].used) {
+            size_t h = (size_t)((unsigned long long)ix->tab[i].key * 0x9E3779B97F4A7C15ull >> 20) & (nx.cap - 1);
+            while (nx.tab[h].used) h = (h + 1) & (nx.cap - 1);
+            nx.tab[h] = ix->tab[i]; nx.used++;
+        }
+        free(ix->tab); *ix = nx;
+    }
+    size_t h = (size_t)((unsigned long long)key * 0x9E3779B97F4A7C15ull >> 20) & (ix->cap - 1);
+    while (ix->tab[h].used && ix->tab[h].key != key) h = (h + 1) & (ix->cap - 1);
+    if (!ix->tab[h].used) {
+        if (!create) return NULL;
+        ix->tab[h].used = 1; ix->tab[h].key = key; ix->used++;
+    }
+    return &ix->tab[h];
+}
+static void ix_add(lmindex_t *ix, int type, double x, double y, double cell, int log_index)
+{
+    lmcell_t *c = ix_find(ix, ix_key(type, ix_coord(x, cell), ix_coord(y, cell)), 1);
+    if (c->n == c->cap) { c->cap = c->cap ? 2 * c->cap : 8; c->it = realloc(c->it, (size_t)c->cap * sizeof(int)); }
+    c->it[c->n++] = log_index;
+}
+static void ix_free(lmindex_t *ix)
+{
+    for (size_t i = 0; i < ix->cap; i++) free(ix->tab[i].it);
+    free(ix->tab); memset(ix, 0, sizeof *ix);
+}
+
 /* ---- PoseGraphSLAM  dual_bot_mapper.py:261-326 -------------------------------------- */
+/* the list scan of :294-318 through the index: same first match (lowest list index), found in the 3 x 3 cells around the query */
+static long first_match_indexed(mapper_t *m, graph_t *g, long idx, int agent, int lm_type, double nx, double ny)
+{
+    if (idx - m->last_closure[agent] < m->min_poses_between) return -1;     /* :304 (true or false for every landmark alike) */
+    const double cell = m->closure_radius * (1.0 + 1e-9);
+    const long cx = ix_coord(nx, cell), cy = ix_coord(ny, cell);
+    long best = -1;
+    for (long dy = -1; dy <= 1; dy++) for (long dx = -1; dx <= 1; dx++) {
+        const lmcell_t *c = ix_find(&g->ix, ix_key(lm_type, cx + dx, cy + dy), 0);
+        if (!c) continue;
+        for (int k = 0; k < c->n; k++) {
+            const long i = c->it[k];
+            if (best >= 0 && i > best) break;
+            const landmark_t *l = &g->lms[i];
+            if (idx - l->idx < m->min_poses_between) break;                 /* :300 (later entries are newer still) */
+            const double dist = sqrt(pow(nx - l->x, 2.0) + pow(ny - l->y, 2.0));   /* :308 */
+            if (dist < m->closure_radius) { best = i; break; }                  /* :309 */
+        }
+    }
+    return best;
+}
+
 static int check_closure(mapper_t *m, graph_t *g, long idx, int agent, int lm_type,
                          double nx, double ny, double *cdx, double *cdy)
 {
-    for (long i = 0; i < g->n_lms; i++) {
+    const int indexed = m->use_index && m->closure_radius > 0;
+    long i0 = 0, i1 = g->n_lms;
+    if (indexed) {                                                      /* the scan below then visits exactly the match */
+        const long b = first_match_indexed(m, g, idx, agent, lm_type, nx, ny);
+        if (b < 0) return 0;
+        i0 = b; i1 = b + 1;
+    }
+    for (long i = i0; i < i1; i++) {
         const landmark_t *l = &g->lms[i];
         if (l->type != lm_type) continue;                              /* :296 */
         if (idx - l->idx < m->min_poses_between) continue;              /* :300 */
@@ -156,6 +230,7 @@ static int add_pose(mapper_t *m, graph_t *g, double x, double y, int agent, int 
             g->cap_lms = g->cap_lms ? 2 * g->cap_lms : 256;
             g->lms = realloc(g->lms, g->cap_lms * sizeof(landmark_t));
         }
+        if (m->use_index && m->closure_radius > 0) ix_add(&g->ix, lm_type, x, y, m->closure_radius * (1.0 + 1e-9), (int)g->n_lms);
         g->lms[g->n_lms++] = (landmark_t){x, y, lm_type, idx};          /* :288 */
     }
     return closed;
@@ -201,7 +276,7 @@ void qso_set_closure_params(mapper_t *m, double radius, long min_between, double
 void qso_destroy(mapper_t *m)
 {
     if (!m) return;
-    for (int g = 0; g < m->n_graphs; g++) { free(m->graphs[g].lms); free(m->graphs[g].cls); }
+    for (int g = 0; g < m->n_graphs; g++) { free(m->graphs[g].lms); free(m->graphs[g].cls); ix_free(&m->graphs[g].ix); }
     free(m->grid); free(m->hits); free(m->misses); free(m->stamps); free(m->graphs); free(m->offset_x);
     free(m->drift); free(m->last_closure); free(m->zone); free(m->zone_n); free(m->pkt_count);
     free(m->ekf); free(m->ekf_prev);
@@ -209,6 +284,8 @@ void qso_destroy(mapper_t *m)
     free(m);
 }
 
+/* closure search through the spatial index (same closures as the list scan); before the first landmark */
+void qso_use_index(mapper_t *m, int on) { m->use_index = on; }
 void qso_set_offset(mapper_t *m, int bot, double off_x) { m->offset_x[bot] = off_x; }
 void qso_set_owned(mapper_t *m, int lo, int hi) { m->own_lo = lo; m->own_hi = hi; }
 

@@ -36,6 +36,7 @@ def lib():
         L.qso_set_offset.argtypes = [vp, i32, f64]
         L.qso_set_closure_params.argtypes = [vp, f64, i64, f64]
         L.qso_set_owned.argtypes = [vp, i32, i32]
+        L.qso_use_index.argtypes = [vp, i32]
         L.qso_feed.restype = i32
         L.qso_feed.argtypes = [vp, vp, i32]
         L.qso_feed_stream.restype = i64
@@ -113,6 +114,11 @@ class OracleMapper:
     def set_owned(self, lo, hi):
         """One shard of a replicated-pose-graph deployment: add_pose for every packet, rays/zones/EKF for agents lo..hi."""
         lib().qso_set_owned(self._h, lo, hi)
+
+    def use_index(self, on=True):
+        """Closure search through a spatial index over self.landmarks instead of the reference's list scan (:294): the same
+        closures, not the reference's algorithm -- for the `indexed` leg of the CPU baseline.  Before the first landmark."""
+        lib().qso_use_index(self._h, int(bool(on)))
 
     def set_closure_params(self, radius=0.6, min_between=30, correction=0.5):
         """Other values of CLOSURE_RADIUS / MIN_POSES_BETWEEN / CLOSURE_CORRECTION (:99-101); before the first packet."""

@@ -201,3 +201,37 @@ def test_pure_python_restatement_equals_reference_fixtures(name):
     assert (pm.grid == o.grid).all()
     for b in (1, 2):
         assert np.abs(np.array(pm.drift[b]) - o.drift(b)).max() == 0.0
+
+
+def test_indexed_closure_search_equals_the_list_scan():
+    """The optional spatial index of the CPU restatement (the `indexed` leg of bench.py's cpu_baseline) finds the reference's
+    first match: closures, landmarks, drift and grid are those of the list scan (:294-318) on the session, five laps, a long
+    cycled stream, 40 bots in one pose graph, other closure constants, and an adversarial stream."""
+    import importlib
+    from conftest import PKG_NAME
+    replay = importlib.import_module(PKG_NAME + ".replay")
+    session, _ = replay.telemetry_csv_to_packets()
+    cases = [("session", session, 2, 0, None), ("cycled", replay.cycle_stream(session, 30000), 2, 0, None),
+             ("40 bots, one graph", replay.multi_bot_stream(None, 40, 20000, pitch=1.0, origin=(-8.0, -8.0), tiles_per_row=5), 40, 0, None),
+             ("13 bots, graphs of 2", replay.multi_bot_stream(None, 13, 12000, pitch=8.0, origin=(-10.0, -10.0), tiles_per_row=4), 13, 2, (0.3, 5, 0.25)),
+             ("no cool-down", replay.cycle_stream(session, 8000), 2, 0, (0.6, 0, 1.0)),
+             ("adversarial", replay.adversarial_stream(20000, seed=5, lo=-10, hi=10), 2, 0, (1.0, 31, 0.5))]
+    for name, stream, bots, bpg, params in cases:
+        out = []
+        for ix in (False, True):
+            o = orc.OracleMapper(512, 0.05, -12.8, -12.8, 0.0, max_agent=bots, bots_per_graph=bpg)
+            if params:
+                o.set_closure_params(*params)
+            o.use_index(ix)
+            o.feed_stream(stream)
+            out.append(o)
+        a, b = out
+        n_cl = 0
+        for g in range(a.n_graphs):
+            ia, ca = a.closures(g); ib, cb = b.closures(g)
+            assert ia.shape == ib.shape and (ia == ib).all() and (ca == cb).all(), name
+            la, ta = a.landmarks(g); lb, tb = b.landmarks(g)
+            assert (ta == tb).all() and (la == lb).all(), name
+            n_cl += len(ia)
+        assert n_cl > 0, name
+        assert (a.grid == b.grid).all() and all((a.drift(k) == b.drift(k)).all() for k in range(1, bots + 1)), name
