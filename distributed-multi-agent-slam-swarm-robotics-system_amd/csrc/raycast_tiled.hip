@@ -288,7 +288,7 @@ qs_scatter_kernel(size_t n, QsBatch b, QtWorkspace ws, int size, unsigned long l
 // ---- experiment (off in production: -DQT_CLIP=1 builds it, tools/ab_raster_clip.sh measures it) ----------
 // Clip a record's walk to its tile in closed form: the walk of dual_bot_mapper.py:166-178 in major / minor form has, after t
 // steps, minor offset m(t) = (2 t dmin + dmaj - 1) div (2 dmaj) and error term E(t) = dmaj - dmin + m(t) dmaj - t dmin
-// (oracle-checked for every |d| <= 40; the in-tile steps are one interval [ta, tb] because both coordinates are monotone).
+// (checked on the CPU against the step-by-step walk for every |d| <= 40; the in-tile steps are one interval [ta, tb] because both coordinates are monotone).
 #ifndef QT_CLIP
 #define QT_CLIP 0
 #endif
