@@ -107,6 +107,10 @@ SIGNATURES = {
     "qs_sparse_fuse_plan": (_i32, [_vp, _vp, _vp, C.POINTER(_vp), C.POINTER(_sz)]),
     "qs_sparse_fuse_apply": (_i32, [_vp]),
     "qs_fused_counts_buffer": (_i32, [_vp, C.POINTER(_vp), C.POINTER(_sz)]),
+    "qs_rccl_unique_id": (_i32, [_vp]),
+    "qs_rccl_comm_init": (_i32, [_vp, _vp, _i32, _i32, C.POINTER(_vp)]),
+    "qs_rccl_comm_destroy": (_i32, [_vp]),
+    "qs_sparse_fuse_rccl": (_i32, [_vp, _vp, _i32, _i32, _vp]),
     "qs_grid_to_pcd": (_i32, [_vp, _vp, _i32, _i32, _f64, _f64, _f64, _vp, _sz, C.POINTER(_sz)]),
     "qs_rasterise": (_i32, [_vp, _vp, _sz, _f64, _vp, _vp, _vp]),
     "qs_icp": (_i32, [_vp, _vp, _sz, _vp, _sz, _f64, _i32, _f64, _f64, _vp, _vp, _vp, _vp]),

@@ -30,6 +30,8 @@ __host__ __device__ inline double qs_double_from_ord(unsigned long long k)
 #define QS_ORD_MIN_IDENT 0xffffffffffffffffull   // identity for atomicMin
 #define QS_ORD_MAX_IDENT 0ull                    // identity for atomicMax
 
+struct QsNcclId { char internal[QS_RCCL_ID_BYTES]; };     // ncclUniqueId (rccl.h), passed by value to ncclCommInitRank
+
 // ---- per pose-graph device state (PoseGraphSLAM, dual_bot_mapper.py:261-271) -------------
 // The landmark list is kept twice: as the reference's insertion-ordered log (read-back, and
 // the fallback scan), and as a spatial index: a directory (hash table over the bucket cells) of buckets

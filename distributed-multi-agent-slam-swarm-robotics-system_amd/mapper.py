@@ -284,6 +284,29 @@ class QuasarMapper:
         self._chk(self._L.qs_fused_counts(self._h, C.byref(p), C.byref(b)), "qs_fused_counts")
         return p.value, b.value
 
+    # -- the same fuse with RCCL behind the C ABI (hosts without torch; csrc/rccl_fuse.hip) -------------------------------
+    @staticmethod
+    def rccl_unique_id():
+        out = np.zeros(128, dtype=np.uint8)
+        check(None, _lib.load().qs_rccl_unique_id(_ptr(out)), "qs_rccl_unique_id")
+        return out
+
+    def rccl_comm_init(self, unique_id, world, rank):
+        uid = np.ascontiguousarray(unique_id, dtype=np.uint8)
+        comm = C.c_void_p()
+        self._chk(self._L.qs_rccl_comm_init(self._h, _ptr(uid), world, rank, C.byref(comm)), "qs_rccl_comm_init")
+        return comm
+
+    def rccl_comm_destroy(self, comm):
+        self._chk(self._L.qs_rccl_comm_destroy(comm), "qs_rccl_comm_destroy")
+
+    def sparse_fuse_rccl(self, comm, world, rank):
+        """One sparse fuse over RCCL -> dict(blocks_own, payload_bytes, sent_bytes, received_bytes)."""
+        st = np.zeros(4, dtype=np.uint64)
+        self._chk(self._L.qs_sparse_fuse_rccl(self._h, comm, world, rank, _ptr(st)), "qs_sparse_fuse_rccl")
+        self._map_version += 1
+        return dict(zip(("blocks_own", "payload_bytes", "sent_bytes", "received_bytes"), (int(v) for v in st)))
+
     def fused_counts_buffer(self):
         """(device address, bytes) of the fused counters as they stand (no snapshot); address 0 before the first fuse."""
         p, b = C.c_void_p(), C.c_size_t()

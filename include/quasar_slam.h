@@ -201,6 +201,17 @@ int qs_sparse_fuse_begin(qs_ctx *ctx, int32_t world, int32_t rank, void **bitmap
 int qs_sparse_fuse_plan(qs_ctx *ctx, uint32_t *n_blocks /* [world] */, size_t *offsets /* [world + 1] */,
                         void **payload_dev, size_t *block_bytes);
 int qs_sparse_fuse_apply(qs_ctx *ctx);
+/* The same fuse with its two exchanges on RCCL, for hosts that are not torch (dist.py drives the three steps above through
+ * torch.distributed): one process per GPU, one communicator over the node's xGMI links.  qs_rccl_unique_id on rank 0, the 128
+ * bytes to every rank by whatever channel the host has, qs_rccl_comm_init on every rank, then qs_sparse_fuse_rccl as often as the
+ * map is to be fused: ncclAllGather of the bitmaps, one group of ncclSend / ncclRecv for the packed blocks (point to point, all
+ * links at once), the fold.  stats (may be NULL): {blocks packed, bytes packed, bytes sent, bytes received} of this rank.
+ * RCCL is loaded on demand (dlopen): QS_E_NODEV if it is absent.  Untested beyond one rank: the build has one GPU. */
+#define QS_RCCL_ID_BYTES 128
+int qs_rccl_unique_id(uint8_t out[QS_RCCL_ID_BYTES]);
+int qs_rccl_comm_init(qs_ctx *ctx, const uint8_t id[QS_RCCL_ID_BYTES], int32_t world, int32_t rank, void **comm);
+int qs_rccl_comm_destroy(void *comm);
+int qs_sparse_fuse_rccl(qs_ctx *ctx, void *comm, int32_t world, int32_t rank, uint64_t stats[4]);
 /* the fused counters as they stand (no snapshot is taken): the sum over the ranks after a fuse; NULL before the first one */
 int qs_fused_counts_buffer(qs_ctx *ctx, void **fused_dev, size_t *bytes);
 /* MapMerger.grid_to_pcd  server_nodes/map_merger.py:64-85: cells > 50 -> (col*res+ox,

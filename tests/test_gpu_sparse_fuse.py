@@ -290,3 +290,28 @@ def test_bench_ranks_rehearsed_on_one_gpu_sparse(extra):
     else:
         assert f["algorithm"] == "sparse" and 0 < f["payload_frac_of_dense_map"] <= 0.05, f
         assert f["sent_bytes_per_gpu"] >= f["payload_bytes_per_gpu"] * (n - 1)
+
+
+def test_sparse_fuse_over_rccl_behind_the_c_abi_single_rank(pkg):
+    """qs_sparse_fuse_rccl (csrc/rccl_fuse.hip): the fuse with its exchanges on RCCL inside the library, for hosts without
+    torch.  One GPU means one rank: this pins that RCCL loads on demand, a communicator comes up, the collective runs on
+    the context's stream and the fused counters accumulate deltas over two fuses -- the multi-rank exchange itself is the
+    protocol test_dist_cpu.py and the N-context tests pin, here with ncclSend / ncclRecv in the copies' place."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "session_512.npz"), allow_pickle=False)
+    pk = g["datagrams"][:, :42]
+    o = orc.OracleMapper(512, 0.05, -12.8, -12.8, 0.0)
+    with pkg.QuasarMapper(512, 0.05, -12.8, -12.8) as m:
+        m.dirty_tracking(True)
+        comm = m.rccl_comm_init(pkg.QuasarMapper.rccl_unique_id(), 1, 0)
+        try:
+            half = len(pk) // 2
+            for lo, hi in ((0, half), (half, len(pk))):
+                m.ingest_array(pk[lo:hi]); o.feed_stream(pk[lo:hi])
+                own, _ = m.dirty_blocks()
+                st = m.sparse_fuse_rccl(comm, 1, 0)
+                assert st["blocks_own"] == own > 0 and st["payload_bytes"] == own * 768 and st["sent_bytes"] == 0
+                h, mi = m.counts()                                   # the fused view: what the ranks' deltas add up to
+                assert (h == o.hits).all() and (mi == o.misses).all() and (m.grid_i8() == o.grid).all()
+            assert m.sparse_fuse_rccl(comm, 1, 0)["blocks_own"] == 0
+        finally:
+            m.rccl_comm_destroy(comm)

@@ -7,7 +7,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 CS=$ROOT/distributed-multi-agent-slam-swarm-robotics-system_amd/csrc
 mkdir -p $ROOT/ab_libs /tmp/abobj_$NAME
 OBJS=""
-for f in qs_api decode slam raycast raycast_tiled grid_ops sparse_fuse ekf ekf_scan frontier icp diag; do
+for f in qs_api decode slam raycast raycast_tiled grid_ops sparse_fuse ekf ekf_scan frontier icp diag rccl_fuse; do
   if [[ " $* " == *" $f.hip "* ]]; then
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math $FLAGS -c $CS/$f.hip -o /tmp/abobj_$NAME/$f.o
     OBJS="$OBJS /tmp/abobj_$NAME/$f.o"
