@@ -131,7 +131,10 @@ SIGNATURES = {
 
 
 def load():
-    """dlopen the HIP library and declare every entry point.  Raises if it is absent."""
+    """dlopen the HIP library and declare every entry point.  Raises if it is absent.
+    A process that also uses torch must import torch BEFORE the first call of this function: the torch wheel bundles its
+    own HIP runtime, and once the system's (which this library links) has initialised the GPU, torch's reports
+    "No HIP GPUs are available".  dist.py and bench.py import torch first; a host that only maps never needs it."""
     global _lib
     if _lib is not None:
         return _lib

@@ -26,6 +26,8 @@
 // node index over their first matches is the reference's first match.  Landmarks of a type the
 // directory has no slab for (type > 5) live in a side list that every query also scans.
 #include "qs_internal.h"
+#include <cstdlib>
+#include <cstring>
 
 #define LL_MAX 0x7fffffffffffffffll
 #define IDX_BLOCK QS_SLAM_IDX_BLOCK
@@ -935,6 +937,391 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
 #undef CH_PHASE_END
 }
 
+// ---- the chain, free-running form (graphs with at most CH_AGW agents) ---------------------------------------------------------
+// The windowed kernel above synchronises every role once per window.  It does not have to: a closure decision needs its agent's
+// own drift (the owner's registers) and the landmarks at least MIN_POSES_BETWEEN nodes older than the query, and
+//   * landmarks enter the index in node order, so whatever the index holds is a PREFIX of self.landmarks;
+//   * the first match in list order (:294-318) is the lowest node index among the matches.
+// Hence a match found among the landmarks the index already holds is FINAL -- every landmark still on its way is newer than
+// all of those -- and only a query that finds nothing has to wait until every landmark it may see has arrived.  On the
+// reference's workloads nearly every query finds a match laps old, so:
+//   owner waves (one per agent)  run their agent's recurrence at their own pace: next own event, pose, query the index (entries
+//                  up to the committer's frontier), closure, next.  Every own event -- closing or not -- goes, with its final
+//                  pose, into the agent's LDS ring; s_prog[a] tells how far the agent has got.
+//   the committer (one wave)     takes events in NODE order as far as every agent has got, up to 32 at a time: closure records
+//                  (:317), the landmark log (:288), the bucket index; then -- its stores complete -- moves the frontier: the node
+//                  index up to which the index is complete and visible.
+// An owner that finds no match below the frontier while the frontier is still short of its limit waits for the committer and asks
+// again; the owner with the oldest pending event never waits for anyone (everything older is final), so the scheme cannot
+// lock up; a full ring holds its owner back until the committer -- which then has work -- drains it.
+#define FR_RING 64
+#define FR_BATCH 64
+// Every wait of this kernel ends by the argument above.  A kernel that never ends would take the GPU with it, so the waits are
+// bounded all the same (~1 s): a wave that runs out of patience leaves a mark in QS_CNT_SLAM_ROUNDS (bit 40) and goes on --
+// the results are then wrong and every parity check says so -- instead of hanging.
+#define FR_SPIN_MAX (1u << 24)
+#define FR_SPIN(cond) do { unsigned int sp_ = 0; while (cond) { if (++sp_ > FR_SPIN_MAX) { if (lane == 0) atomicAdd(&counters[QS_CNT_SLAM_ROUNDS], 1ull << 40); break; } \
+                                                               __builtin_amdgcn_s_sleep(1); } } while (0)
+
+// one query: the reference's first match among the landmarks of type qtype with node index <= eff, within the radius of
+// (qx, qy); lane = (bucket of the 3 x 3 neighbourhood, entry of that bucket's current node).  LL_MAX: none.
+template <bool DENSE>
+__device__ inline long long free_query(const QsGraphDev *Gp, QsNodeG g_nodes, QsU32G g_next, const QsBucketGeom &bg, double qx, double qy,
+                                       int qtype, long long eff, double r2thr, long long nm, long long nl, int lane, double &wx, double &wy,
+                                       unsigned long long &st_misc)
+{
+    const int nbk = lane / QS_NODE_CAP, se = lane % QS_NODE_CAP;
+    const int last_lane = min(nbk * QS_NODE_CAP + QS_NODE_CAP - 1, 63);
+    const int nb_dx = (nbk % 3) - 1, nb_dy = (nbk / 3) - 1;
+    int qcx, qcy;
+    const bool indexed = bucket_cell(qx, qy, qtype, bg, qcx, qcy);
+    unsigned int node = 0;
+    if (indexed && lane < 9 * QS_NODE_CAP) node = 1u + (unsigned int)bucket_key(qtype, qcx + nb_dx, qcy + nb_dy, bg);
+    long long best = LL_MAX, gbest = LL_MAX;
+    double bx = 0, by = 0;
+    const int dense_after = (int)((nl >> 9) > 8 ? ((nl >> 9) < 100000 ? (nl >> 9) : 100000) : 8);
+    int rounds = 0;
+    bool dense = false;
+    while (__ballot(node != 0)) {
+        if (DENSE && rounds++ == dense_after) { dense = true; break; }
+        long long id = LL_MAX, lastid = LL_MAX;
+        double nx = 0, ny = 0;
+        unsigned int nxt = 0;
+        if (node) {
+            const QsNodeG nd = g_nodes + node;
+            id = nd->idx[se]; lastid = nd->idx[QS_NODE_CAP - 1]; nx = nd->x[se]; ny = nd->y[se]; nxt = g_next[node];
+        }
+        const bool inlim = node != 0 && id <= eff;                       // empty slots read as a huge index
+        bool newhit = false;
+        if (inlim && best == LL_MAX) {
+            const double dx = qx - nx, dy = qy - ny;
+            if (dx * dx + dy * dy < r2thr) { best = id; bx = nx; by = ny; newhit = true; }   // :308-309
+        }
+        if (__ballot(newhit)) {
+            const long long v = (unsigned long long)eff >> 32 ? wave_min_nonneg_i64(newhit ? best : LL_MAX)
+                                                               : (long long)wave_min_u32(newhit ? (unsigned int)best : 0xffffffffu);
+            gbest = v < gbest ? v : gbest;
+        }
+        const unsigned long long hitm = __ballot(best != LL_MAX);
+        const unsigned long long limm = __ballot(inlim);
+        const bool b_hit = ((hitm >> (nbk * QS_NODE_CAP)) & 0x7full) != 0;
+        const bool b_full = ((limm >> last_lane) & 1ull) != 0;
+        if (node) node = (b_hit || !b_full || nxt == 0 || lastid >= gbest) ? 0u : nxt;
+    }
+    wx = 0; wy = 0;
+    if (DENSE && dense) {
+        // self.landmarks in insertion order (:294), a wave wide; the scan ends at the first entry that is too new
+        gbest = LL_MAX;
+        const QS_GLOBAL long long *const g_idx = (const QS_GLOBAL long long *)Gp->lm_idx;
+        const QS_GLOBAL unsigned char *const g_type = (const QS_GLOBAL unsigned char *)Gp->lm_type;
+        const QS_GLOBAL double *const g_x = (const QS_GLOBAL double *)Gp->lm_x, *const g_y = (const QS_GLOBAL double *)Gp->lm_y;
+        for (long long c0 = 0; c0 < nl; c0 += QS_WAVE) {
+            st_misc++;
+            const long long k0 = c0 + lane;
+            long long i0 = LL_MAX; int t0 = 0; double x0 = 0, y0 = 0;
+            if (k0 < nl) { i0 = g_idx[k0]; t0 = g_type[k0]; x0 = g_x[k0]; y0 = g_y[k0]; }
+            const double ax = qx - x0, ay = qy - y0;
+            const bool ok = i0 <= eff && t0 == qtype && ax * ax + ay * ay < r2thr;
+            const unsigned long long m0 = __ballot(ok);
+            if (m0) { const int w = __ffsll((long long)m0) - 1; gbest = rl64(i0, w); wx = rlf64(x0, w); wy = rlf64(y0, w); break; }
+            if (__ballot(k0 < nl && i0 > eff)) break;
+        }
+        return gbest;
+    }
+    if (gbest != LL_MAX) {
+        const int w = __ffsll((long long)__ballot(best == gbest)) - 1;
+        wx = rlf64(bx, w); wy = rlf64(by, w);
+    }
+    if (nm > 0) {                                                       // landmarks outside the directory (types > 5): linear, rare
+        const unsigned int *const misc = Gp->misc;
+        const long long *const lm_idx = Gp->lm_idx;
+        const unsigned char *const lm_type = Gp->lm_type;
+        const double *const lm_x = Gp->lm_x, *const lm_y = Gp->lm_y;
+        for (long long c0 = 0; c0 < nm; c0 += QS_WAVE) {
+            st_misc++;
+            const long long k2 = c0 + lane;
+            bool cand = false, beyond = false;
+            long long li = LL_MAX; double lx = 0, ly = 0;
+            if (k2 < nm) {
+                const unsigned int slot = misc[k2];
+                li = lm_idx[slot];
+                beyond = li > eff;
+                if (!beyond && lm_type[slot] == qtype) {
+                    lx = lm_x[slot]; ly = lm_y[slot];
+                    const double dx = qx - lx, dy = qy - ly;
+                    cand = dx * dx + dy * dy < r2thr;
+                }
+            }
+            const unsigned long long cm = __ballot(cand);
+            if (cm) {
+                const int w = __ffsll((long long)cm) - 1;
+                const long long widx = rl64(li, w);
+                if (widx < gbest) { gbest = widx; wx = rlf64(lx, w); wy = rlf64(ly, w); }
+                break;
+            }
+            if (__ballot(beyond)) break;
+        }
+    }
+    return gbest;
+}
+
+__device__ inline long long lds_ld64(const long long *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ inline void lds_st64(long long *p, long long v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ inline unsigned int lds_ld32(const unsigned int *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ inline void lds_st32(unsigned int *p, unsigned int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+template <bool DENSE>
+__global__ void __launch_bounds__(CH_THREADS)
+qs_slam_chain_free_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGeom bg, int bots_per_graph,
+                          int max_agent, int min_between, double r2thr, double corr,
+                          double *__restrict__ drift, long long *__restrict__ last_closure,
+                          unsigned long long *__restrict__ counters, int raw_pose, unsigned int *__restrict__ pile_flag)
+{
+    const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    QsGraphDev *const Gp = graphs + g;
+    const int bot0 = g * bots_per_graph + 1;
+    const int nb = min(bots_per_graph, max_agent - bot0 + 1);
+
+    // every own event of agent a, in its order: slot (ordinal mod FR_RING) of the agent's ring
+    __shared__ long long r_idx[CH_AGW][FR_RING], r_midx[CH_AGW][FR_RING];       // node index; matched landmark (LL_MAX: no closure)
+    __shared__ double r_x[CH_AGW][FR_RING], r_y[CH_AGW][FR_RING];               // final pose: what the landmark is stored at (:288)
+    __shared__ double r_cdx[CH_AGW][FR_RING], r_cdy[CH_AGW][FR_RING];           // the closure's correction (:314-315)
+    __shared__ int r_type[CH_AGW][FR_RING];
+    __shared__ unsigned int s_push[CH_AGW], s_cons[CH_AGW];                     // events pushed by the owner / taken by the committer
+    __shared__ long long s_prog[CH_AGW];          // node index of the agent's next event not yet in its ring (LL_MAX: none left)
+    __shared__ long long s_frontier;              // every landmark with node index <= this is in the index, complete and visible
+    __shared__ long long s_nmisc, s_nlms;         // side-list / log entries that go with that frontier
+
+    const unsigned int e0 = sb.ev_base[g], e1 = sb.ev_base[g + 1];
+    if (tid < CH_AGW) { s_push[tid] = 0; s_cons[tid] = 0; s_prog[tid] = tid < nb ? (e0 < e1 ? sb.ev_node[e0] : LL_MAX) : LL_MAX; }
+    if (tid == 0) { s_frontier = e0 < e1 ? sb.ev_node[e0] - 1 : LL_MAX; s_nmisc = Gp->n_misc; s_nlms = Gp->n_lms; }
+    __syncthreads();
+
+    if (wave >= 1 && wave <= nb) {
+        // =================================== owner of agent a ===================================
+        const int a = wave - 1;
+        double c_dx = drift[2 * (bot0 + a)], c_dy = drift[2 * (bot0 + a) + 1];
+        long long c_last = last_closure[bot0 + a];
+        const unsigned int pos0 = sb.agent_ev[bot0 + a];
+        unsigned int pos = pos0, pushed = 0;
+        const QsNodeG g_nodes = (QsNodeG)Gp->nodes;
+        const QsU32G g_next = (QsU32G)Gp->nd_next;
+        unsigned long long st_misc = 0, st_wait = 0;
+        // ring space for n more entries: the committer has taken all but FR_RING - n of what was written.  The count it has taken
+        // is cached (an LDS round trip only when the ring looks full); before any wait everything written so far is published --
+        // the committer cannot free slots it cannot see behind entries it has not been told of.
+        unsigned int cons_c = 0, published = 0;
+        long long prog_pub = LL_MAX;
+        auto publish = [&](long long nxt) {
+            // what is handed over is the ring (LDS): the release is an LDS one -- a general release would also wait for this
+            // wave's global stores (the per-bot closure list, which nobody in this kernel reads) to be acknowledged
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            if (lane == 0) {
+                __hip_atomic_store(&s_push[a], pushed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_store(&s_prog[a], nxt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            published = pushed; prog_pub = nxt;
+        };
+#ifdef QS_FREE_PROF
+        unsigned long long pf_wait = 0, pf_query = 0, pf_total0 = __builtin_amdgcn_s_memtime();
+#endif
+        auto wait_space = [&](unsigned int n, long long pending_idx) {
+            if (pushed + n - cons_c <= FR_RING) return;
+            cons_c = lds_ld32(&s_cons[a]);
+            if (pushed + n - cons_c <= FR_RING) return;
+#ifdef QS_FREE_PROF
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime();
+#endif
+            if (published != pushed || prog_pub != pending_idx) publish(pending_idx);
+            FR_SPIN(pushed + n - (cons_c = lds_ld32(&s_cons[a])) > FR_RING);
+#ifdef QS_FREE_PROF
+            pf_wait += __builtin_amdgcn_s_memtime() - t_;
+#endif
+        };
+        // the next chunk's events are requested while this chunk's are dealt with
+        auto load_chunk = [&](unsigned int q0, int &ag, long long &idx, int &type, double &px, double &py, long long &next_first) {
+            const unsigned int q = q0 + lane;
+            const bool have = q < e1;
+            ag = have ? (int)sb.ev_agent[q] : -1;
+            idx = have ? sb.ev_node[q] : LL_MAX;
+            type = have ? (int)sb.ev_type[q] : 0;
+            px = have ? sb.ev_px[q] : 0; py = have ? sb.ev_py[q] : 0;
+            // (a lower bound on the agent's next event while a chunk's are being dealt with and after: the next chunk's first)
+            next_first = q0 + QS_WAVE < e1 ? sb.ev_node[q0 + QS_WAVE] : LL_MAX;
+        };
+        int ag_n = -1, type_n = 0; long long idx_n = LL_MAX, nf_n = LL_MAX; double px_n = 0, py_n = 0;
+        if (e0 < e1) load_chunk(e0, ag_n, idx_n, type_n, px_n, py_n, nf_n);
+        for (unsigned int q0 = e0; q0 < e1; q0 += QS_WAVE) {
+            const int ag = ag_n, type = type_n;
+            const long long idx = idx_n, next_first = nf_n;
+            const double px = px_n, py = py_n;
+            if (q0 + QS_WAVE < e1) load_chunk(q0 + QS_WAVE, ag_n, idx_n, type_n, px_n, py_n, nf_n);
+            unsigned long long m = __ballot(ag == a);
+            while (m) {
+                // own events before the first one that may close (:304) keep the current drift: posed and written together
+                const unsigned long long elig = m & __ballot(idx - c_last >= min_between);
+                const int f = elig ? __ffsll((long long)elig) - 1 : 64;
+                const unsigned long long grp = f < 64 ? (m & ((1ull << f) - 1)) : m;
+                if (grp) {
+                    const unsigned int n = (unsigned int)__popcll(grp);
+                    wait_space(n, rl64(idx, __ffsll((long long)grp) - 1));
+                    if ((grp >> lane) & 1) {
+                        const unsigned int s = (pushed + (unsigned int)__popcll(grp & ((1ull << lane) - 1))) % FR_RING;
+                        r_idx[a][s] = idx; r_type[a][s] = type; r_midx[a][s] = LL_MAX;
+                        r_x[a][s] = raw_pose ? px : px + c_dx;                    // rx += cdx  :856
+                        r_y[a][s] = raw_pose ? py : py + c_dy;                    // ry += cdy  :857
+                    }
+                    pushed += n;
+                    m &= ~grp;
+                }
+                if (f == 64) break;
+                // ---- the event in lane f may close a loop ----
+                const long long qidx = rl64(idx, f);
+                const double spx = rlf64(px, f), spy = rlf64(py, f);
+                const double qx = raw_pose ? spx : spx + c_dx, qy = raw_pose ? spy : spy + c_dy;
+                const int qtype = __builtin_amdgcn_readlane(type, f);
+                // :300 -- and a node never sees its own landmark (appended after the check, :288): with MIN_POSES_BETWEEN < 1
+                // the newest landmark a query can see is still the one before it
+                const long long limit = qidx - (min_between > 1 ? min_between : 1);
+                long long gbest; double wx, wy;
+#ifdef QS_FREE_PROF
+                const unsigned long long tq_ = __builtin_amdgcn_s_memtime();
+#endif
+                for (;;) {
+                    const long long fr = lds_ld64(&s_frontier);
+                    const long long nm = s_nmisc, nl = DENSE ? s_nlms : 0;
+                    gbest = free_query<DENSE>(Gp, g_nodes, g_next, bg, qx, qy, qtype, fr < limit ? fr : limit, r2thr, nm, nl, lane, wx, wy, st_misc);
+                    if (gbest != LL_MAX || fr >= limit) break;                      // a match below the frontier is final; so is "none" once all are in
+                    st_wait++;
+                    if (published != pushed || prog_pub != qidx) publish(qidx);     // (the committer has to get past this agent's older events)
+                    FR_SPIN(lds_ld64(&s_frontier) < limit);
+                }
+#ifdef QS_FREE_PROF
+                pf_query += __builtin_amdgcn_s_memtime() - tq_;
+#endif
+                double cdx = 0, cdy = 0;
+                if (gbest != LL_MAX) {
+                    const double ex = wx - qx, ey = wy - qy;                        // :311-312
+                    cdx = ex * corr; cdy = ey * corr;                               // :314-315
+                    c_dx += cdx; c_dy += cdy; c_last = qidx;                        // :911-914, :318
+                    if (lane == 0) { sb.acl_node[pos] = qidx; sb.acl_dx[pos] = c_dx; sb.acl_dy[pos] = c_dy; }
+                    pos++;
+                }
+                wait_space(1, qidx);
+                if (lane == 0) {
+                    const unsigned int s = pushed % FR_RING;
+                    r_idx[a][s] = qidx; r_type[a][s] = qtype; r_midx[a][s] = gbest;
+                    r_x[a][s] = qx; r_y[a][s] = qy;                                 // stored with the pose it was matched at (:288)
+                    r_cdx[a][s] = cdx; r_cdy[a][s] = cdy;
+                }
+                pushed++;
+                m &= ~(1ull << f);
+                publish(m ? rl64(idx, __ffsll((long long)m) - 1) : next_first);     // one publication per decision
+            }
+            if (published != pushed || prog_pub != next_first) publish(next_first);
+        }
+        if (lane == 0) {
+            lds_st64(&s_prog[a], LL_MAX);
+            drift[2 * (bot0 + a)] = c_dx; drift[2 * (bot0 + a) + 1] = c_dy; last_closure[bot0 + a] = c_last;
+            sb.acl_cnt[bot0 + a] = pos - pos0;
+            if (st_misc) atomicAdd(&counters[QS_CNT_SLAM_MISC_ITERS], st_misc);
+            if (st_wait) atomicAdd(&counters[QS_CNT_SLAM_ROUNDS], st_wait);
+#ifdef QS_FREE_PROF
+            if (a == 0) { atomicAdd(&counters[QS_CNT_SLAM_CYC_A], pf_wait); atomicAdd(&counters[QS_CNT_SLAM_CYC_B], pf_query);
+                          atomicAdd(&counters[QS_CNT_SLAM_NODE_ITERS], __builtin_amdgcn_s_memtime() - pf_total0); }
+#endif
+        }
+    } else if (wave == CH_INS) {
+        // =================================== the committer ===================================
+        const QsGraphDev G = *Gp;
+        long long n_lms = G.n_lms, n_misc = G.n_misc, n_cls = G.n_cls;
+        unsigned int pool = G.nodes_used;
+        bool pile = false;
+        unsigned long long st_batches = 0;
+        const unsigned long long t0_cyc = __builtin_amdgcn_s_memtime(), t0_real = __builtin_amdgcn_s_memrealtime();
+        unsigned int e = e0, idle = 0;
+#ifdef QS_FREE_PROF
+        unsigned long long pf_idle = 0;
+#endif
+        while (e < e1) {
+            const unsigned int q = e + lane;
+            const bool have = lane < FR_BATCH && q < e1;
+            const long long node = have ? sb.ev_node[q] : LL_MAX;
+            const int ag = have ? (int)sb.ev_agent[q] : 0;
+            // an event is ready when its agent has got past it; the batch is the ready PREFIX (node order)
+            const bool ready = have && lds_ld64(&s_prog[ag]) > node;
+            const unsigned long long rm = __ballot(ready);
+            const int k = rm == ~0ull ? 64 : (int)__builtin_ctzll(~rm);                 // leading ready lanes
+            if (k == 0) {
+                if (++idle > FR_SPIN_MAX) { if (lane == 0) atomicAdd(&counters[QS_CNT_SLAM_ROUNDS], 1ull << 40); break; }   // (never: see FR_SPIN)
+#ifdef QS_FREE_PROF
+                pf_idle++;
+#endif
+                __builtin_amdgcn_s_sleep(1);
+                continue;
+            }
+            idle = 0;
+            const bool inw = lane < k;
+            // position of the lane's event among its agent's events of the batch -> its ring slot
+            unsigned int rnk = 0, cnt = 0;
+            int ldr = lane;
+            for (unsigned long long rem = __ballot(inw); rem;) {
+                const int ld = __ffsll((long long)rem) - 1;
+                const int aa = __builtin_amdgcn_readlane(ag, ld);
+                const unsigned long long grp = __ballot(inw && ag == aa);
+                if (inw && ag == aa) { rnk = (unsigned int)__popcll(grp & ((1ull << lane) - 1)); cnt = (unsigned int)__popcll(grp); ldr = ld; }
+                rem &= ~grp;
+            }
+            const unsigned int base = inw ? s_cons[ag] : 0;
+            const unsigned int s = (base + rnk) % FR_RING;
+            const int type = inw ? r_type[ag][s] : 0;
+            const double x = inw ? r_x[ag][s] : 0, y = inw ? r_y[ag][s] : 0;
+            const long long midx = inw ? r_midx[ag][s] : LL_MAX;
+            const double cdx = inw ? r_cdx[ag][s] : 0, cdy = inw ? r_cdy[ag][s] : 0;
+            // ---- closure records, in node order  (:317) ----
+            const bool closes = inw && midx != LL_MAX;
+            const unsigned long long cmask = __ballot(closes);
+            if (closes) {
+                const long long slot = n_cls + __popcll(cmask & ((1ull << lane) - 1));
+                if (slot < G.cap_cls) {
+                    G.cl_lm_idx[slot] = midx; G.cl_node_idx[slot] = node; G.cl_dx[slot] = cdx; G.cl_dy[slot] = cdy;
+                    G.cl_agent[slot] = (unsigned char)(bot0 + ag);
+                }
+            }
+            n_cls += __popcll(cmask);
+            // ---- self.landmarks.append(...)  :288, and the bucket index ----
+            int cx, cy;
+            const long long kb = (inw && bucket_cell(x, y, type, bg, cx, cy)) ? bucket_key(type, cx, cy, bg) : -1;
+            chain_insert_lanes(G, inw, lane, node, kb, x, y, type, k, lane, n_lms, n_misc, pool, pile);
+            // ---- everything above complete, then the frontier moves ----
+            // (workgroup scope: the readers are waves of this workgroup, on this CU; what is needed is that the stores are done)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (inw && ldr == lane) lds_st32(&s_cons[ag], base + cnt);
+            const long long next_node = (k < FR_BATCH && e + k < e1) ? rl64(node, k < 63 ? k : 63)
+                                                                     : (e + k < e1 ? sb.ev_node[e + k] : LL_MAX);
+            if (lane == 0) {
+                s_nmisc = n_misc; s_nlms = n_lms;
+                lds_st64(&s_frontier, next_node == LL_MAX ? LL_MAX : next_node - 1);
+            }
+            e += k;
+            st_batches++;
+        }
+        if (lane == 0) {
+            atomicAdd(&counters[QS_CNT_CLOSURES], (unsigned long long)(n_cls - G.n_cls));
+            atomicAdd(&counters[QS_CNT_LANDMARKS], (unsigned long long)(n_lms - G.n_lms));
+            atomicAdd(&counters[QS_CNT_SLAM_WINDOWS], st_batches);
+#ifdef QS_FREE_PROF
+            atomicAdd(&counters[QS_CNT_SLAM_CYC_C], pf_idle);
+#endif
+            atomicAdd(&counters[QS_CNT_SLAM_CYCLES], __builtin_amdgcn_s_memtime() - t0_cyc);
+            atomicAdd(&counters[QS_CNT_SLAM_REALTIME], __builtin_amdgcn_s_memrealtime() - t0_real);
+            Gp->n_nodes = G.n_nodes + sb.acc_total[g];
+            Gp->n_cls = n_cls; Gp->n_lms = n_lms; Gp->n_misc = n_misc; Gp->nodes_used = pool;
+            if (pile && pile_flag) *pile_flag = 1u;
+        }
+    }
+}
+
 // ---- pose: rx, ry of every accepted record (dual_bot_mapper.py:855-857) ---------------------------
 // drift of the record's bot = drift after that bot's last closure at a node index < the record's
 // (a closure at node j is applied to packets after j, :910-914), else the drift at batch start.
@@ -1028,8 +1415,15 @@ hipError_t qs_launch_slam(qs_ctx *c, size_t n, bool raw_pose)
                            c->bots_per_graph, c->cfg.max_agent, c->win, c->cfg.min_poses_between, c->r2_threshold,                          \
                            c->cfg.closure_correction, c->d_drift, c->d_last_closure, c->d_counters, raw_pose ? 1 : 0, c->d_flags + 1)
     const bool one = c->bots_per_graph <= CH_AGW;
-    if (c->pile_mode) { if (one) CH_LAUNCH(true, true); else CH_LAUNCH(false, true); }
+    // QS_CHAIN_MODE=window: the per-window kernel also for graphs of at most CH_AGW agents (default: the free-running form)
+    static const bool free_mode = [] { const char *e = getenv("QS_CHAIN_MODE"); return !(e && strcmp(e, "window") == 0); }();
+#define FR_LAUNCH(DENSE_) hipLaunchKernelGGL((qs_slam_chain_free_kernel<DENSE_>), dim3(G), dim3(CH_THREADS), 0, c->stream, c->d_graphs, sb, c->bg, \
+                           c->bots_per_graph, c->cfg.max_agent, c->cfg.min_poses_between, c->r2_threshold,                                  \
+                           c->cfg.closure_correction, c->d_drift, c->d_last_closure, c->d_counters, raw_pose ? 1 : 0, c->d_flags + 1)
+    if (one && free_mode) { if (c->pile_mode) FR_LAUNCH(true); else FR_LAUNCH(false); }
+    else if (c->pile_mode) { if (one) CH_LAUNCH(true, true); else CH_LAUNCH(false, true); }
     else { if (one) CH_LAUNCH(true, false); else CH_LAUNCH(false, false); }
+#undef FR_LAUNCH
 #undef CH_LAUNCH
     t_chain.stop();
     if (raw_pose) return hipGetLastError();

@@ -10,6 +10,7 @@ import struct
 
 import numpy as np
 import pytest
+import torch  # before the HIP library: torch bundles its own HIP runtime, and whichever of the two is loaded first has to be torch's
 
 from conftest import GOLDEN, ROOT, load_pkg
 from oracle import oracle as orc
