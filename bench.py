@@ -386,12 +386,15 @@ def secondary_64_bots(pkg, replay, torch, dev, side, args, G, counts, bpg=2, ste
     n_graphs = m.n_graphs
     m.close()
     win = max(cnt["slam_windows"], 1)
+    free_running = (bpg or 64) <= 13 and os.environ.get("QS_CHAIN_MODE", "") != "window"
     return {"workload": f"configs[2]: 64 bots (own generator runs, seeds 42..105) in {n_graphs} pose graph{'s' if n_graphs > 1 else ''}, own room "
                         f"tiles, {G}x{G} grid, {B} packets/step, same stages",
             "pose_graphs_per_gpu": n_graphs, "bots_per_graph": bpg or 64,
             "value": B * steps / el, "unit": "packets/s", "steps": steps, "warmup": warm, "ms_per_step": el / steps * 1e3,
-            "stages_ms_per_step": st, "closures_per_step": cnt["closures"], "slam_windows_per_step": cnt["slam_windows"],
-            "chain_cycles_per_window": cnt["slam_cycles"] / win,
+            "stages_ms_per_step": st, "closures_per_step": cnt["closures"], "chain_form": "free-running" if free_running else "windowed",
+            ("chain_committer_batches_per_step" if free_running else "slam_windows_per_step"): cnt["slam_windows"],
+            ("chain_cycles_per_decision" if free_running else "chain_cycles_per_window"):
+                (cnt["slam_cycles"] / n_graphs) / (max(cnt["closures"], 1) / (n_graphs * (bpg or 64))) if free_running else cnt["slam_cycles"] / win,
             "parity_checked": not bad,
             "cpu_baseline": {"value": B / cpu_s, "unit": "packets/s", "cores": 1, "kind": "port",
                              "sample": f"one whole step, oracle/oracle.c, {cpu_s:.1f} s"}}
@@ -583,9 +586,17 @@ def run_rank(args):
         "frac_counter": (ray_traffic / (ray_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (ray_traffic and ray_ms > 0) else None,
         "counter_source": f"replayed from profiles/{prof_round}/{prof_dir}/pmc_*.csv (rocprofv3 --pmc passes of this command), NOT measured in this run"
                           if ray_traffic else None}
+    # which form of the chain kernel ran (csrc/slam.hip): graphs of at most 13 agents take the free-running form -- one owner wave
+    # per agent, no per-window barrier -- unless QS_CHAIN_MODE=window; larger graphs the windowed form
+    agents_per_graph = bpg or max_agent
+    free_running = agents_per_graph <= 13 and os.environ.get("QS_CHAIN_MODE", "") != "window"
     if chain_ms >= ray_ms:
         dom_ms = chain_ms
         win = max(cnt["slam_windows"], 1)
+        # sequential decisions of ONE agent's recurrence per launch (the agents of a graph decide side by side), and the kernel's
+        # cycles per such decision; windowed form: its unit is the window (every role synchronises once per window)
+        decisions = max(cnt["closures"], 1) / max(m.n_graphs * agents_per_graph, 1)
+        cyc_unit = (cnt["slam_cycles"] / max(m.n_graphs, 1)) / decisions if free_running else cnt["slam_cycles"] / win
         roofline = {
             "bound": "latency", "kernel": "qs_slam_chain_kernel (K4 loop-closure recurrence)",
             "achieved": alg_bytes / (dom_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -594,10 +605,15 @@ def run_rank(args):
             "algorithmic_bytes_per_launch": alg_bytes,
             "algorithmic_bytes_rule": "whole step's D4 bytes (42 B/packet + in-bounds cell writes x (8 B stamp RMW + 8 B counter RMW)) over the "
                                       "dominant kernel's duration: the step cannot finish before this kernel does",
-            "nature": "latency-bound sequential recurrence, not a bandwidth kernel: one 1024-thread workgroup per pose graph",
+            "nature": "latency-bound sequential recurrence, not a bandwidth kernel: one workgroup per pose graph" +
+                      (" -- free-running form: one owner wave per agent runs that agent's closure decisions one after the other, "
+                       "a committer wave inserts behind them; no barrier per window" if free_running else
+                       " -- windowed form: every role synchronises once per window of < MIN_POSES_BETWEEN nodes"),
+            "form": "free-running" if free_running else "windowed",
             "workgroups": m.n_graphs, "cus_occupied": min(m.n_graphs, N_CU), "cus_total": N_CU,
-            "windows_per_launch": cnt["slam_windows"], "cycles_per_window": cnt["slam_cycles"] / win,
-            "ns_per_window": dom_ms * 1e6 / win,
+            "closures_per_launch": cnt["closures"], "sequential_decisions_per_agent": decisions if free_running else None,
+            "cycles_per_decision" if free_running else "cycles_per_window": cyc_unit,
+            "committer_batches_per_launch" if free_running else "windows_per_launch": cnt["slam_windows"],
             "note": "achieved / peak / frac keep the HBM form the contract asks for (the step's D4 bytes over this kernel's time against "
                     "8 TB/s); the kernel is a recurrence bound by the dependent chain between two decisions, priced in latency_floor"}
         try:
@@ -610,12 +626,13 @@ def run_rank(args):
                 lat["readlane_step"] + 2 * lat["readlane_step"] + 3 * lat["fma_f64"]
             floor = lat["barrier_5_waves"] + lat["lds_read"] + lat["l2_load"] + lat["lds_read"] + valu
             roofline["latency_floor"] = {
-                "cycles_per_window": floor, "achieved_cycles_per_window": cnt["slam_cycles"] / win,
-                "achieved_over_floor": cnt["slam_cycles"] / win / floor, "frac_of_floor": floor / (cnt["slam_cycles"] / win),
-                "floor_ms_per_launch": floor * win / max(m.n_graphs, 1) / (lat["clock_mhz"] * 1e3),
-                "chain": "1 workgroup barrier (5 waves) + 1 LDS read (the window) + 22 dependent VALU / cross-lane steps (pose -> nine bucket "
+                "cycles_per_decision": floor, "achieved_cycles_per_decision": cyc_unit,
+                "achieved_over_floor": cyc_unit / floor, "frac_of_floor": floor / cyc_unit,
+                "floor_ms_per_launch": floor * (decisions if free_running else win / max(m.n_graphs, 1)) / (lat["clock_mhz"] * 1e3),
+                "chain": "1 workgroup barrier (5 waves; the windowed form's: the free-running form has none, its hand-over is an LDS "
+                         "word) + 1 LDS read (the events / the frontier) + 22 dependent VALU / cross-lane steps (pose -> nine bucket "
                          "addresses; distance test; wave-wide minimum; winner; closure) + 1 L2 round trip (node rows) + 1 LDS write "
-                         "the next window can see",
+                         "the next decision's consumer can see",
                 "measured_cycles": lat,
                 "source": "qs_diag_latencies (csrc/diag.hip), measured in this run; one decision per window is the minimum the "
                           "recurrence allows (dual_bot_mapper.py:292-326: a closure moves every later pose of its agent)"}

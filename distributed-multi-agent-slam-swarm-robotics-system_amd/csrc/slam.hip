@@ -945,17 +945,17 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
 // Hence a match found among the landmarks the index already holds is FINAL -- every landmark still on its way is newer than
 // all of those -- and only a query that finds nothing has to wait until every landmark it may see has arrived.  On the
 // reference's workloads nearly every query finds a match laps old, so:
-//   owner waves (one per agent)  run their agent's recurrence at their own pace: next own event, pose, query the index (entries
-//                  up to the committer's frontier), closure, next.  Every own event -- closing or not -- goes, with its final
-//                  pose, into the agent's LDS ring; s_prog[a] tells how far the agent has got.
-//   the committer (one wave)     takes events in NODE order as far as every agent has got, up to 32 at a time: closure records
-//                  (:317), the landmark log (:288), the bucket index; then -- its stores complete -- moves the frontier: the node
-//                  index up to which the index is complete and visible.
+//   owner waves (one per agent)  run their agent's recurrence at their own pace: the agent's next event that may close (:304),
+//                  its pose, a query of the index (entries up to the committer's frontier), the closure, next.  An owner hands
+//                  over its DECISIONS only (closing node, matched landmark, correction: an LDS ring) and how far it has decided.
+//   the committer (one wave)     takes events in NODE order as far as every agent has decided, up to 64 at a time: it keeps every
+//                  agent's drift as the decisions it has passed leave it (the owner's additions in the owner's order), poses
+//                  the events, writes closure records (:317), the landmark log (:288), the bucket index; then -- its stores
+//                  complete -- moves the frontier: the node index up to which the index is complete and visible.
 // An owner that finds no match below the frontier while the frontier is still short of its limit waits for the committer and asks
 // again; the owner with the oldest pending event never waits for anyone (everything older is final), so the scheme cannot
-// lock up; a full ring holds its owner back until the committer -- which then has work -- drains it.
+// lock up; a full decision ring holds its owner back until the committer -- which then has work -- drains it.
 #define FR_RING 64
-#define FR_BATCH 64
 // Every wait of this kernel ends by the argument above.  A kernel that never ends would take the GPU with it, so the waits are
 // bounded all the same (~1 s): a wave that runs out of patience leaves a mark in QS_CNT_SLAM_ROUNDS (bit 40) and goes on --
 // the results are then wrong and every parity check says so -- instead of hanging.
@@ -1082,61 +1082,50 @@ qs_slam_chain_free_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuc
     const int bot0 = g * bots_per_graph + 1;
     const int nb = min(bots_per_graph, max_agent - bot0 + 1);
 
-    // every own event of agent a, in its order: slot (ordinal mod FR_RING) of the agent's ring
-    __shared__ long long r_idx[CH_AGW][FR_RING], r_midx[CH_AGW][FR_RING];       // node index; matched landmark (LL_MAX: no closure)
-    __shared__ double r_x[CH_AGW][FR_RING], r_y[CH_AGW][FR_RING];               // final pose: what the landmark is stored at (:288)
-    __shared__ double r_cdx[CH_AGW][FR_RING], r_cdy[CH_AGW][FR_RING];           // the closure's correction (:314-315)
-    __shared__ int r_type[CH_AGW][FR_RING];
-    __shared__ unsigned int s_push[CH_AGW], s_cons[CH_AGW];                     // events pushed by the owner / taken by the committer
-    __shared__ long long s_prog[CH_AGW];          // node index of the agent's next event not yet in its ring (LL_MAX: none left)
+    // An owner hands the committer its DECISIONS only -- (closing node, matched landmark, correction), in the agent's order, in a
+    // ring of FR_RING slots -- and how far it has decided (s_prog).  Everything else about an event follows from those: the
+    // committer walks the events in node order, keeps every agent's drift as the decisions it has passed leave it (the same
+    // additions in the same order as the owner's: the same doubles), and poses, logs, indexes and records from that.
+    __shared__ long long q_idx[CH_AGW][FR_RING], q_midx[CH_AGW][FR_RING];       // closing node; matched landmark's node
+    __shared__ double q_cdx[CH_AGW][FR_RING], q_cdy[CH_AGW][FR_RING];           // the closure's correction (:314-315)
+    __shared__ unsigned int s_push[CH_AGW], s_cons[CH_AGW];                     // decisions pushed by the owner / taken by the committer
+    __shared__ long long s_prog[CH_AGW];          // every event of the agent with a node index below this is decided (LL_MAX: all)
     __shared__ long long s_frontier;              // every landmark with node index <= this is in the index, complete and visible
     __shared__ long long s_nmisc, s_nlms;         // side-list / log entries that go with that frontier
+    // committer's own: every agent's drift as of the events it has passed, and where the agent's next closure record goes
+    __shared__ double c_ddx[CH_AGW], c_ddy[CH_AGW];
+    __shared__ unsigned int c_apos[CH_AGW];
 
     const unsigned int e0 = sb.ev_base[g], e1 = sb.ev_base[g + 1];
-    if (tid < CH_AGW) { s_push[tid] = 0; s_cons[tid] = 0; s_prog[tid] = tid < nb ? (e0 < e1 ? sb.ev_node[e0] : LL_MAX) : LL_MAX; }
+    if (tid < CH_AGW) {
+        s_push[tid] = 0; s_cons[tid] = 0;
+        s_prog[tid] = tid < nb ? (e0 < e1 ? sb.ev_node[e0] : LL_MAX) : LL_MAX;
+        if (tid < nb) { c_ddx[tid] = drift[2 * (bot0 + tid)]; c_ddy[tid] = drift[2 * (bot0 + tid) + 1]; c_apos[tid] = sb.agent_ev[bot0 + tid]; }
+    }
     if (tid == 0) { s_frontier = e0 < e1 ? sb.ev_node[e0] - 1 : LL_MAX; s_nmisc = Gp->n_misc; s_nlms = Gp->n_lms; }
     __syncthreads();
 
     if (wave >= 1 && wave <= nb) {
         // =================================== owner of agent a ===================================
+        __builtin_amdgcn_s_setprio(3);             // the decisions are the critical path
         const int a = wave - 1;
         double c_dx = drift[2 * (bot0 + a)], c_dy = drift[2 * (bot0 + a) + 1];
         long long c_last = last_closure[bot0 + a];
-        const unsigned int pos0 = sb.agent_ev[bot0 + a];
-        unsigned int pos = pos0, pushed = 0;
+        unsigned int pushed = 0, cons_c = 0;
         const QsNodeG g_nodes = (QsNodeG)Gp->nodes;
         const QsU32G g_next = (QsU32G)Gp->nd_next;
         unsigned long long st_misc = 0, st_wait = 0;
-        // ring space for n more entries: the committer has taken all but FR_RING - n of what was written.  The count it has taken
-        // is cached (an LDS round trip only when the ring looks full); before any wait everything written so far is published --
-        // the committer cannot free slots it cannot see behind entries it has not been told of.
-        unsigned int cons_c = 0, published = 0;
-        long long prog_pub = LL_MAX;
+#ifdef QS_FREE_PROF
+        unsigned long long pf_wait = 0, pf_query = 0, pf_total0 = __builtin_amdgcn_s_memtime();
+#endif
         auto publish = [&](long long nxt) {
-            // what is handed over is the ring (LDS): the release is an LDS one -- a general release would also wait for this
-            // wave's global stores (the per-bot closure list, which nobody in this kernel reads) to be acknowledged
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            // what is handed over is the decision ring (LDS), written by this wave just before: the LDS unit takes a wave's
+            // operations in the order they were issued, so all that is needed is that the compiler keeps that order
+            __asm__ volatile("" ::: "memory");
             if (lane == 0) {
                 __hip_atomic_store(&s_push[a], pushed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 __hip_atomic_store(&s_prog[a], nxt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
-            published = pushed; prog_pub = nxt;
-        };
-#ifdef QS_FREE_PROF
-        unsigned long long pf_wait = 0, pf_query = 0, pf_total0 = __builtin_amdgcn_s_memtime();
-#endif
-        auto wait_space = [&](unsigned int n, long long pending_idx) {
-            if (pushed + n - cons_c <= FR_RING) return;
-            cons_c = lds_ld32(&s_cons[a]);
-            if (pushed + n - cons_c <= FR_RING) return;
-#ifdef QS_FREE_PROF
-            const unsigned long long t_ = __builtin_amdgcn_s_memtime();
-#endif
-            if (published != pushed || prog_pub != pending_idx) publish(pending_idx);
-            FR_SPIN(pushed + n - (cons_c = lds_ld32(&s_cons[a])) > FR_RING);
-#ifdef QS_FREE_PROF
-            pf_wait += __builtin_amdgcn_s_memtime() - t_;
-#endif
         };
         // the next chunk's events are requested while this chunk's are dealt with
         auto load_chunk = [&](unsigned int q0, int &ag, long long &idx, int &type, double &px, double &py, long long &next_first) {
@@ -1146,8 +1135,7 @@ qs_slam_chain_free_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuc
             idx = have ? sb.ev_node[q] : LL_MAX;
             type = have ? (int)sb.ev_type[q] : 0;
             px = have ? sb.ev_px[q] : 0; py = have ? sb.ev_py[q] : 0;
-            // (a lower bound on the agent's next event while a chunk's are being dealt with and after: the next chunk's first)
-            next_first = q0 + QS_WAVE < e1 ? sb.ev_node[q0 + QS_WAVE] : LL_MAX;
+            next_first = q0 + QS_WAVE < e1 ? sb.ev_node[q0 + QS_WAVE] : LL_MAX;   // a lower bound on the agent's next event after this chunk
         };
         int ag_n = -1, type_n = 0; long long idx_n = LL_MAX, nf_n = LL_MAX; double px_n = 0, py_n = 0;
         if (e0 < e1) load_chunk(e0, ag_n, idx_n, type_n, px_n, py_n, nf_n);
@@ -1156,29 +1144,18 @@ qs_slam_chain_free_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuc
             const long long idx = idx_n, next_first = nf_n;
             const double px = px_n, py = py_n;
             if (q0 + QS_WAVE < e1) load_chunk(q0 + QS_WAVE, ag_n, idx_n, type_n, px_n, py_n, nf_n);
-            unsigned long long m = __ballot(ag == a);
-            while (m) {
-                // own events before the first one that may close (:304) keep the current drift: posed and written together
-                const unsigned long long elig = m & __ballot(idx - c_last >= min_between);
-                const int f = elig ? __ffsll((long long)elig) - 1 : 64;
-                const unsigned long long grp = f < 64 ? (m & ((1ull << f) - 1)) : m;
-                if (grp) {
-                    const unsigned int n = (unsigned int)__popcll(grp);
-                    wait_space(n, rl64(idx, __ffsll((long long)grp) - 1));
-                    if ((grp >> lane) & 1) {
-                        const unsigned int s = (pushed + (unsigned int)__popcll(grp & ((1ull << lane) - 1))) % FR_RING;
-                        r_idx[a][s] = idx; r_type[a][s] = type; r_midx[a][s] = LL_MAX;
-                        r_x[a][s] = raw_pose ? px : px + c_dx;                    // rx += cdx  :856
-                        r_y[a][s] = raw_pose ? py : py + c_dy;                    // ry += cdy  :857
-                    }
-                    pushed += n;
-                    m &= ~grp;
-                }
-                if (f == 64) break;
-                // ---- the event in lane f may close a loop ----
+            const unsigned long long own = __ballot(ag == a);
+            unsigned long long done = 0;                                            // own lanes decided so far
+            // the agent's events that may close a loop (:304); the ones before the first of them need no decision
+            unsigned long long elig = own & __ballot(idx - c_last >= min_between);
+            while (elig) {
+                // (read early and relaxed: its latency hides behind the set-up below -- an older value is only more cautious --, and
+                // the acquire that orders the node loads after it comes with the query)
+                const long long fr0 = __hip_atomic_load(&s_frontier, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const int f = __ffsll((long long)elig) - 1;
                 const long long qidx = rl64(idx, f);
                 const double spx = rlf64(px, f), spy = rlf64(py, f);
-                const double qx = raw_pose ? spx : spx + c_dx, qy = raw_pose ? spy : spy + c_dy;
+                const double qx = raw_pose ? spx : spx + c_dx, qy = raw_pose ? spy : spy + c_dy;   // rx += cdx  :856-857
                 const int qtype = __builtin_amdgcn_readlane(type, f);
                 // :300 -- and a node never sees its own landmark (appended after the check, :288): with MIN_POSES_BETWEEN < 1
                 // the newest landmark a query can see is still the one before it
@@ -1187,43 +1164,52 @@ qs_slam_chain_free_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuc
 #ifdef QS_FREE_PROF
                 const unsigned long long tq_ = __builtin_amdgcn_s_memtime();
 #endif
-                for (;;) {
-                    const long long fr = lds_ld64(&s_frontier);
+                for (long long fr = fr0;; fr = lds_ld64(&s_frontier)) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");            // the index as of that frontier, not older
                     const long long nm = s_nmisc, nl = DENSE ? s_nlms : 0;
                     gbest = free_query<DENSE>(Gp, g_nodes, g_next, bg, qx, qy, qtype, fr < limit ? fr : limit, r2thr, nm, nl, lane, wx, wy, st_misc);
                     if (gbest != LL_MAX || fr >= limit) break;                      // a match below the frontier is final; so is "none" once all are in
                     st_wait++;
-                    if (published != pushed || prog_pub != qidx) publish(qidx);     // (the committer has to get past this agent's older events)
+                    publish(qidx);                                                  // (the committer has to get past this agent's older events)
                     FR_SPIN(lds_ld64(&s_frontier) < limit);
                 }
 #ifdef QS_FREE_PROF
                 pf_query += __builtin_amdgcn_s_memtime() - tq_;
 #endif
-                double cdx = 0, cdy = 0;
+                done |= (2ull << f) - 1;                                            // (lanes up to f: decided)
                 if (gbest != LL_MAX) {
                     const double ex = wx - qx, ey = wy - qy;                        // :311-312
-                    cdx = ex * corr; cdy = ey * corr;                               // :314-315
+                    const double cdx = ex * corr, cdy = ey * corr;                  // :314-315
                     c_dx += cdx; c_dy += cdy; c_last = qidx;                        // :911-914, :318
-                    if (lane == 0) { sb.acl_node[pos] = qidx; sb.acl_dx[pos] = c_dx; sb.acl_dy[pos] = c_dy; }
-                    pos++;
+                    if (pushed - cons_c >= FR_RING) {                               // the decision ring looks full
+                        cons_c = lds_ld32(&s_cons[a]);
+                        if (pushed - cons_c >= FR_RING) {
+#ifdef QS_FREE_PROF
+                            const unsigned long long t_ = __builtin_amdgcn_s_memtime();
+#endif
+                            publish(qidx);
+                            FR_SPIN(pushed - (cons_c = lds_ld32(&s_cons[a])) >= FR_RING);
+#ifdef QS_FREE_PROF
+                            pf_wait += __builtin_amdgcn_s_memtime() - t_;
+#endif
+                        }
+                    }
+                    if (lane == 0) {
+                        const unsigned int s = pushed % FR_RING;
+                        q_idx[a][s] = qidx; q_midx[a][s] = gbest; q_cdx[a][s] = cdx; q_cdy[a][s] = cdy;
+                    }
+                    pushed++;
                 }
-                wait_space(1, qidx);
-                if (lane == 0) {
-                    const unsigned int s = pushed % FR_RING;
-                    r_idx[a][s] = qidx; r_type[a][s] = qtype; r_midx[a][s] = gbest;
-                    r_x[a][s] = qx; r_y[a][s] = qy;                                 // stored with the pose it was matched at (:288)
-                    r_cdx[a][s] = cdx; r_cdy[a][s] = cdy;
-                }
-                pushed++;
-                m &= ~(1ull << f);
-                publish(m ? rl64(idx, __ffsll((long long)m) - 1) : next_first);     // one publication per decision
+                // decided: everything of this agent below its next event that may close (or, failing one in this chunk, below the
+                // next chunk's first event)
+                elig = own & ~done & __ballot(idx - c_last >= min_between);
+                publish(elig ? rl64(idx, __ffsll((long long)elig) - 1) : next_first);
             }
-            if (published != pushed || prog_pub != next_first) publish(next_first);
+            publish(next_first);
         }
+        publish(LL_MAX);
         if (lane == 0) {
-            lds_st64(&s_prog[a], LL_MAX);
             drift[2 * (bot0 + a)] = c_dx; drift[2 * (bot0 + a) + 1] = c_dy; last_closure[bot0 + a] = c_last;
-            sb.acl_cnt[bot0 + a] = pos - pos0;
             if (st_misc) atomicAdd(&counters[QS_CNT_SLAM_MISC_ITERS], st_misc);
             if (st_wait) atomicAdd(&counters[QS_CNT_SLAM_ROUNDS], st_wait);
 #ifdef QS_FREE_PROF
@@ -1245,13 +1231,15 @@ qs_slam_chain_free_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuc
 #endif
         while (e < e1) {
             const unsigned int q = e + lane;
-            const bool have = lane < FR_BATCH && q < e1;
+            const bool have = q < e1;
             const long long node = have ? sb.ev_node[q] : LL_MAX;
             const int ag = have ? (int)sb.ev_agent[q] : 0;
-            // an event is ready when its agent has got past it; the batch is the ready PREFIX (node order)
+            const int type_l = have ? (int)sb.ev_type[q] : 0;                          // (one round trip for all five fields)
+            const double px_l = have ? sb.ev_px[q] : 0, py_l = have ? sb.ev_py[q] : 0;
+            // an event is ready when its agent has decided past it; the batch is the ready PREFIX (node order)
             const bool ready = have && lds_ld64(&s_prog[ag]) > node;
             const unsigned long long rm = __ballot(ready);
-            const int k = rm == ~0ull ? 64 : (int)__builtin_ctzll(~rm);                 // leading ready lanes
+            const int k = rm == ~0ull ? 64 : (int)__builtin_ctzll(~rm);
             if (k == 0) {
                 if (++idle > FR_SPIN_MAX) { if (lane == 0) atomicAdd(&counters[QS_CNT_SLAM_ROUNDS], 1ull << 40); break; }   // (never: see FR_SPIN)
 #ifdef QS_FREE_PROF
@@ -1262,22 +1250,41 @@ qs_slam_chain_free_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuc
             }
             idle = 0;
             const bool inw = lane < k;
-            // position of the lane's event among its agent's events of the batch -> its ring slot
-            unsigned int rnk = 0, cnt = 0;
-            int ldr = lane;
+            const int type = inw ? type_l : 0;
+            const double px = inw ? px_l : 0, py = inw ? py_l : 0;
+            // ---- every agent of the batch: its drift along its events, its decisions that fall into the batch ----
+            double dx = 0, dy = 0, cdx = 0, cdy = 0;
+            long long midx = LL_MAX;
             for (unsigned long long rem = __ballot(inw); rem;) {
                 const int ld = __ffsll((long long)rem) - 1;
                 const int aa = __builtin_amdgcn_readlane(ag, ld);
-                const unsigned long long grp = __ballot(inw && ag == aa);
-                if (inw && ag == aa) { rnk = (unsigned int)__popcll(grp & ((1ull << lane) - 1)); cnt = (unsigned int)__popcll(grp); ldr = ld; }
-                rem &= ~grp;
+                const unsigned long long La = __ballot(inw && ag == aa);
+                rem &= ~La;
+                double cur_dx = c_ddx[aa], cur_dy = c_ddy[aa];
+                unsigned int dc = s_cons[aa];
+                const unsigned int dp = lds_ld32(&s_push[aa]);
+                unsigned int apos = c_apos[aa];
+                unsigned long long left = La;                                        // lanes of aa not yet given their drift
+                while (dc != dp) {
+                    const unsigned int sl = dc % FR_RING;
+                    const long long qi = q_idx[aa][sl];
+                    const unsigned long long lm = La & __ballot(node == qi);
+                    if (!lm) break;                                                  // the agent's next decision is about a later event
+                    const int lc = __ffsll((long long)lm) - 1;
+                    const unsigned long long upto = left & ((2ull << lc) - 1);       // the closing event and the agent's events before it
+                    if ((upto >> lane) & 1) { dx = cur_dx; dy = cur_dy; }            // matched / stored at the pose BEFORE the closure (:288, :308)
+                    const double ecx = q_cdx[aa][sl], ecy = q_cdy[aa][sl];
+                    if (lane == lc) { midx = q_midx[aa][sl]; cdx = ecx; cdy = ecy; }
+                    cur_dx += ecx; cur_dy += ecy;                                    // drift_correction[agent] += ...  :911-914
+                    if (lane == lc) { sb.acl_node[apos] = qi; sb.acl_dx[apos] = cur_dx; sb.acl_dy[apos] = cur_dy; }
+                    apos++;
+                    left &= ~upto;
+                    dc++;
+                }
+                if ((left >> lane) & 1) { dx = cur_dx; dy = cur_dy; }
+                if (lane == ld) { c_ddx[aa] = cur_dx; c_ddy[aa] = cur_dy; c_apos[aa] = apos; lds_st32(&s_cons[aa], dc); }
             }
-            const unsigned int base = inw ? s_cons[ag] : 0;
-            const unsigned int s = (base + rnk) % FR_RING;
-            const int type = inw ? r_type[ag][s] : 0;
-            const double x = inw ? r_x[ag][s] : 0, y = inw ? r_y[ag][s] : 0;
-            const long long midx = inw ? r_midx[ag][s] : LL_MAX;
-            const double cdx = inw ? r_cdx[ag][s] : 0, cdy = inw ? r_cdy[ag][s] : 0;
+            const double x = raw_pose ? px : px + dx, y = raw_pose ? py : py + dy;   // rx += cdx, ry += cdy  :856-857
             // ---- closure records, in node order  (:317) ----
             const bool closes = inw && midx != LL_MAX;
             const unsigned long long cmask = __ballot(closes);
@@ -1296,9 +1303,7 @@ qs_slam_chain_free_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuc
             // ---- everything above complete, then the frontier moves ----
             // (workgroup scope: the readers are waves of this workgroup, on this CU; what is needed is that the stores are done)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            if (inw && ldr == lane) lds_st32(&s_cons[ag], base + cnt);
-            const long long next_node = (k < FR_BATCH && e + k < e1) ? rl64(node, k < 63 ? k : 63)
-                                                                     : (e + k < e1 ? sb.ev_node[e + k] : LL_MAX);
+            const long long next_node = (k < 64 && e + k < e1) ? rl64(node, k < 63 ? k : 63) : (e + k < e1 ? sb.ev_node[e + k] : LL_MAX);
             if (lane == 0) {
                 s_nmisc = n_misc; s_nlms = n_lms;
                 lds_st64(&s_frontier, next_node == LL_MAX ? LL_MAX : next_node - 1);
@@ -1319,6 +1324,7 @@ qs_slam_chain_free_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuc
             Gp->n_cls = n_cls; Gp->n_lms = n_lms; Gp->n_misc = n_misc; Gp->nodes_used = pool;
             if (pile && pile_flag) *pile_flag = 1u;
         }
+        for (int t = lane; t < nb; t += QS_WAVE) sb.acl_cnt[bot0 + t] = c_apos[t] - sb.agent_ev[bot0 + t];
     }
 }
 
