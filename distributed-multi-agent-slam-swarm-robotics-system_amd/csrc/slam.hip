@@ -1070,7 +1070,11 @@ __device__ inline void lds_st64(long long *p, long long v) { __hip_atomic_store(
 __device__ inline unsigned int lds_ld32(const unsigned int *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ inline void lds_st32(unsigned int *p, unsigned int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
-template <bool DENSE>
+// MANY: the graph has more agents than owner waves (up to 255 bots in ONE PoseGraphSLAM).  Owner wave w then runs the agents
+// a = w - 1 (mod n_ow), their events in node order: lane j keeps the state of agent (w - 1) + n_ow j; the decision rings are per
+// agent and short (an agent closes at most once in MIN_POSES_BETWEEN nodes), the progress word is the owner's.
+#define FR_RING_MANY 4
+template <bool MANY, bool DENSE>
 __global__ void __launch_bounds__(CH_THREADS)
 qs_slam_chain_free_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGeom bg, int bots_per_graph,
                           int max_agent, int min_between, double r2thr, double corr,
@@ -1081,51 +1085,56 @@ qs_slam_chain_free_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuc
     QsGraphDev *const Gp = graphs + g;
     const int bot0 = g * bots_per_graph + 1;
     const int nb = min(bots_per_graph, max_agent - bot0 + 1);
+    const int n_ow = min(CH_AGW, nb);               // owner waves in use
+    constexpr int NA = MANY ? QS_MAX_AGENT + 1 : CH_AGW;     // agents a graph of this instantiation can have
+    constexpr int RD = MANY ? FR_RING_MANY : FR_RING;        // decisions an agent can be ahead of the committer
 
     // An owner hands the committer its DECISIONS only -- (closing node, matched landmark, correction), in the agent's order, in a
-    // ring of FR_RING slots -- and how far it has decided (s_prog).  Everything else about an event follows from those: the
+    // ring of RD slots -- and how far it has decided (s_prog).  Everything else about an event follows from those: the
     // committer walks the events in node order, keeps every agent's drift as the decisions it has passed leave it (the same
     // additions in the same order as the owner's: the same doubles), and poses, logs, indexes and records from that.
-    __shared__ long long q_idx[CH_AGW][FR_RING], q_midx[CH_AGW][FR_RING];       // closing node; matched landmark's node
-    __shared__ double q_cdx[CH_AGW][FR_RING], q_cdy[CH_AGW][FR_RING];           // the closure's correction (:314-315)
-    __shared__ unsigned int s_push[CH_AGW], s_cons[CH_AGW];                     // decisions pushed by the owner / taken by the committer
-    __shared__ long long s_prog[CH_AGW];          // every event of the agent with a node index below this is decided (LL_MAX: all)
+    __shared__ long long q_idx[NA][RD], q_midx[NA][RD];                         // closing node; matched landmark's node
+    __shared__ double q_cdx[NA][RD], q_cdy[NA][RD];                             // the closure's correction (:314-315)
+    __shared__ unsigned int s_push[NA], s_cons[NA];                             // decisions pushed by the owner / taken by the committer
+    __shared__ long long s_prog[CH_AGW];          // every event of the owner's agents with a node index below this is decided (LL_MAX: all)
     __shared__ long long s_frontier;              // every landmark with node index <= this is in the index, complete and visible
     __shared__ long long s_nmisc, s_nlms;         // side-list / log entries that go with that frontier
     // committer's own: every agent's drift as of the events it has passed, and where the agent's next closure record goes
-    __shared__ double c_ddx[CH_AGW], c_ddy[CH_AGW];
-    __shared__ unsigned int c_apos[CH_AGW];
+    __shared__ double c_ddx[NA], c_ddy[NA];
+    __shared__ unsigned int c_apos[NA];
+    __shared__ unsigned int c_tag[MANY ? NA : 1];   // MANY: the batch's first event of an agent that is still to be handled (a lane), else ~0
 
     const unsigned int e0 = sb.ev_base[g], e1 = sb.ev_base[g + 1];
-    if (tid < CH_AGW) {
-        s_push[tid] = 0; s_cons[tid] = 0;
-        s_prog[tid] = tid < nb ? (e0 < e1 ? sb.ev_node[e0] : LL_MAX) : LL_MAX;
-        if (tid < nb) { c_ddx[tid] = drift[2 * (bot0 + tid)]; c_ddy[tid] = drift[2 * (bot0 + tid) + 1]; c_apos[tid] = sb.agent_ev[bot0 + tid]; }
+    for (int t = tid; t < NA; t += CH_THREADS) {
+        s_push[t] = 0; s_cons[t] = 0;
+        if (MANY) c_tag[t] = 0xffffffffu;
+        if (t < nb) { c_ddx[t] = drift[2 * (bot0 + t)]; c_ddy[t] = drift[2 * (bot0 + t) + 1]; c_apos[t] = sb.agent_ev[bot0 + t]; }
     }
+    if (tid < CH_AGW) s_prog[tid] = tid < n_ow ? (e0 < e1 ? sb.ev_node[e0] : LL_MAX) : LL_MAX;
     if (tid == 0) { s_frontier = e0 < e1 ? sb.ev_node[e0] - 1 : LL_MAX; s_nmisc = Gp->n_misc; s_nlms = Gp->n_lms; }
     __syncthreads();
 
-    if (wave >= 1 && wave <= nb) {
-        // =================================== owner of agent a ===================================
+    if (wave >= 1 && wave <= n_ow) {
+        // =================================== owner of agent wave - 1 (MANY: of the agents wave - 1 mod n_ow) ===================================
         __builtin_amdgcn_s_setprio(3);             // the decisions are the critical path
         const int a = wave - 1;
-        double c_dx = drift[2 * (bot0 + a)], c_dy = drift[2 * (bot0 + a) + 1];
-        long long c_last = last_closure[bot0 + a];
-        unsigned int pushed = 0, cons_c = 0;
+        // ONE agent: its state in every lane.  MANY: lane j keeps agent a + n_ow j (the authoritative copy; nothing else writes it)
+        const int my_agent = MANY ? a + n_ow * lane : a;
+        const bool my_valid = my_agent < nb;
+        double c_dx = my_valid ? drift[2 * (bot0 + my_agent)] : 0, c_dy = my_valid ? drift[2 * (bot0 + my_agent) + 1] : 0;
+        long long c_last = my_valid ? last_closure[bot0 + my_agent] : 0;
+        unsigned int pushed = 0, cons_c = 0;       // (MANY: of the lane's agent)
         const QsNodeG g_nodes = (QsNodeG)Gp->nodes;
         const QsU32G g_next = (QsU32G)Gp->nd_next;
         unsigned long long st_misc = 0, st_wait = 0;
 #ifdef QS_FREE_PROF
         unsigned long long pf_wait = 0, pf_query = 0, pf_total0 = __builtin_amdgcn_s_memtime();
 #endif
-        auto publish = [&](long long nxt) {
+        auto publish_prog = [&](long long nxt) {
             // what is handed over is the decision ring (LDS), written by this wave just before: the LDS unit takes a wave's
             // operations in the order they were issued, so all that is needed is that the compiler keeps that order
             __asm__ volatile("" ::: "memory");
-            if (lane == 0) {
-                __hip_atomic_store(&s_push[a], pushed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_store(&s_prog[a], nxt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
+            if (lane == 0) __hip_atomic_store(&s_prog[a], nxt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         };
         // the next chunk's events are requested while this chunk's are dealt with
         auto load_chunk = [&](unsigned int q0, int &ag, long long &idx, int &type, double &px, double &py, long long &next_first) {
@@ -1135,7 +1144,7 @@ qs_slam_chain_free_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuc
             idx = have ? sb.ev_node[q] : LL_MAX;
             type = have ? (int)sb.ev_type[q] : 0;
             px = have ? sb.ev_px[q] : 0; py = have ? sb.ev_py[q] : 0;
-            next_first = q0 + QS_WAVE < e1 ? sb.ev_node[q0 + QS_WAVE] : LL_MAX;   // a lower bound on the agent's next event after this chunk
+            next_first = q0 + QS_WAVE < e1 ? sb.ev_node[q0 + QS_WAVE] : LL_MAX;   // a lower bound on the owner's next event after this chunk
         };
         int ag_n = -1, type_n = 0; long long idx_n = LL_MAX, nf_n = LL_MAX; double px_n = 0, py_n = 0;
         if (e0 < e1) load_chunk(e0, ag_n, idx_n, type_n, px_n, py_n, nf_n);
@@ -1144,18 +1153,26 @@ qs_slam_chain_free_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuc
             const long long idx = idx_n, next_first = nf_n;
             const double px = px_n, py = py_n;
             if (q0 + QS_WAVE < e1) load_chunk(q0 + QS_WAVE, ag_n, idx_n, type_n, px_n, py_n, nf_n);
-            const unsigned long long own = __ballot(ag == a);
+            const unsigned long long own = __ballot(ag >= 0 && (MANY ? ag % n_ow : ag) == a);
+            const int st_lane = MANY ? (ag >= 0 ? ag / n_ow : 0) : 0;               // the lane that keeps the event's agent's state
             unsigned long long done = 0;                                            // own lanes decided so far
-            // the agent's events that may close a loop (:304); the ones before the first of them need no decision
-            unsigned long long elig = own & __ballot(idx - c_last >= min_between);
+            // the events that may close a loop (:304: their agent is past its cool-down); the ones before the first need no decision
+            auto eligible = [&]() -> unsigned long long {
+                const long long last_ev = MANY ? __shfl(c_last, st_lane) : c_last;
+                return own & ~done & __ballot(idx - last_ev >= min_between);
+            };
+            unsigned long long elig = eligible();
             while (elig) {
                 // (read early and relaxed: its latency hides behind the set-up below -- an older value is only more cautious --, and
                 // the acquire that orders the node loads after it comes with the query)
                 const long long fr0 = __hip_atomic_load(&s_frontier, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 const int f = __ffsll((long long)elig) - 1;
+                const int qa = MANY ? __builtin_amdgcn_readlane(ag, f) : a;
+                const int ql = MANY ? qa / n_ow : 0;                                // the lane that keeps agent qa's state
                 const long long qidx = rl64(idx, f);
+                const double odx = MANY ? rlf64(c_dx, ql) : c_dx, ody = MANY ? rlf64(c_dy, ql) : c_dy;
                 const double spx = rlf64(px, f), spy = rlf64(py, f);
-                const double qx = raw_pose ? spx : spx + c_dx, qy = raw_pose ? spy : spy + c_dy;   // rx += cdx  :856-857
+                const double qx = raw_pose ? spx : spx + odx, qy = raw_pose ? spy : spy + ody;   // rx += cdx  :856-857
                 const int qtype = __builtin_amdgcn_readlane(type, f);
                 // :300 -- and a node never sees its own landmark (appended after the check, :288): with MIN_POSES_BETWEEN < 1
                 // the newest landmark a query can see is still the one before it
@@ -1170,7 +1187,7 @@ qs_slam_chain_free_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuc
                     gbest = free_query<DENSE>(Gp, g_nodes, g_next, bg, qx, qy, qtype, fr < limit ? fr : limit, r2thr, nm, nl, lane, wx, wy, st_misc);
                     if (gbest != LL_MAX || fr >= limit) break;                      // a match below the frontier is final; so is "none" once all are in
                     st_wait++;
-                    publish(qidx);                                                  // (the committer has to get past this agent's older events)
+                    publish_prog(qidx);                                             // (the committer has to get past this owner's older events)
                     FR_SPIN(lds_ld64(&s_frontier) < limit);
                 }
 #ifdef QS_FREE_PROF
@@ -1180,36 +1197,45 @@ qs_slam_chain_free_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuc
                 if (gbest != LL_MAX) {
                     const double ex = wx - qx, ey = wy - qy;                        // :311-312
                     const double cdx = ex * corr, cdy = ey * corr;                  // :314-315
-                    c_dx += cdx; c_dy += cdy; c_last = qidx;                        // :911-914, :318
-                    if (pushed - cons_c >= FR_RING) {                               // the decision ring looks full
-                        cons_c = lds_ld32(&s_cons[a]);
-                        if (pushed - cons_c >= FR_RING) {
+                    // the agent's decision ring: a slot must be free
+                    unsigned int pq = MANY ? (unsigned int)__builtin_amdgcn_readlane((int)pushed, ql) : pushed;
+                    unsigned int cq = MANY ? (unsigned int)__builtin_amdgcn_readlane((int)cons_c, ql) : cons_c;
+                    if (pq - cq >= (unsigned int)RD) {                              // looks full
+                        cq = lds_ld32(&s_cons[qa]);
+                        if (pq - cq >= (unsigned int)RD) {
 #ifdef QS_FREE_PROF
                             const unsigned long long t_ = __builtin_amdgcn_s_memtime();
 #endif
-                            publish(qidx);
-                            FR_SPIN(pushed - (cons_c = lds_ld32(&s_cons[a])) >= FR_RING);
+                            publish_prog(qidx);
+                            FR_SPIN(pq - (cq = lds_ld32(&s_cons[qa])) >= (unsigned int)RD);
 #ifdef QS_FREE_PROF
                             pf_wait += __builtin_amdgcn_s_memtime() - t_;
 #endif
                         }
                     }
                     if (lane == 0) {
-                        const unsigned int s = pushed % FR_RING;
-                        q_idx[a][s] = qidx; q_midx[a][s] = gbest; q_cdx[a][s] = cdx; q_cdy[a][s] = cdy;
+                        const unsigned int sl = pq % RD;
+                        q_idx[qa][sl] = qidx; q_midx[qa][sl] = gbest; q_cdx[qa][sl] = cdx; q_cdy[qa][sl] = cdy;
                     }
-                    pushed++;
+                    if (!MANY || lane == ql) {
+                        c_dx += cdx; c_dy += cdy; c_last = qidx;                    // :911-914, :318
+                        pushed = pq + 1; cons_c = cq;
+                    }
+                    __asm__ volatile("" ::: "memory");
+                    if (lane == 0) __hip_atomic_store(&s_push[qa], pq + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
-                // decided: everything of this agent below its next event that may close (or, failing one in this chunk, below the
+                // decided: everything of this owner below its next event that may close (or, failing one in this chunk, below the
                 // next chunk's first event)
-                elig = own & ~done & __ballot(idx - c_last >= min_between);
-                publish(elig ? rl64(idx, __ffsll((long long)elig) - 1) : next_first);
+                elig = eligible();
+                publish_prog(elig ? rl64(idx, __ffsll((long long)elig) - 1) : next_first);
             }
-            publish(next_first);
+            publish_prog(next_first);
         }
-        publish(LL_MAX);
+        publish_prog(LL_MAX);
+        if (my_valid && (MANY || lane == 0)) {
+            drift[2 * (bot0 + my_agent)] = c_dx; drift[2 * (bot0 + my_agent) + 1] = c_dy; last_closure[bot0 + my_agent] = c_last;
+        }
         if (lane == 0) {
-            drift[2 * (bot0 + a)] = c_dx; drift[2 * (bot0 + a) + 1] = c_dy; last_closure[bot0 + a] = c_last;
             if (st_misc) atomicAdd(&counters[QS_CNT_SLAM_MISC_ITERS], st_misc);
             if (st_wait) atomicAdd(&counters[QS_CNT_SLAM_ROUNDS], st_wait);
 #ifdef QS_FREE_PROF
@@ -1227,17 +1253,29 @@ qs_slam_chain_free_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuc
         const unsigned long long t0_cyc = __builtin_amdgcn_s_memtime(), t0_real = __builtin_amdgcn_s_memrealtime();
         unsigned int e = e0, idle = 0;
 #ifdef QS_FREE_PROF
-        unsigned long long pf_idle = 0;
+        unsigned long long pf_idle = 0, pf_agents = 0, pf_insert = 0;
 #endif
-        while (e < e1) {
-            const unsigned int q = e + lane;
+        // the events at the head of the list, a lane each: asked for again as soon as it is known how many of them go into the batch,
+        // so that the next 64 arrive while this batch is dealt with
+        long long node = LL_MAX, node_n = LL_MAX;
+        int ag = 0, type_l = 0, ag_n = 0, type_n = 0;
+        double px_l = 0, py_l = 0, px_n = 0, py_n = 0;
+        auto load_events = [&](unsigned int from, long long &nd, int &a_, int &ty, double &x_, double &y_) {
+            const unsigned int q = from + lane;
             const bool have = q < e1;
-            const long long node = have ? sb.ev_node[q] : LL_MAX;
-            const int ag = have ? (int)sb.ev_agent[q] : 0;
-            const int type_l = have ? (int)sb.ev_type[q] : 0;                          // (one round trip for all five fields)
-            const double px_l = have ? sb.ev_px[q] : 0, py_l = have ? sb.ev_py[q] : 0;
+            nd = have ? sb.ev_node[q] : LL_MAX;
+            a_ = have ? (int)sb.ev_agent[q] : 0;
+            ty = have ? (int)sb.ev_type[q] : 0;
+            x_ = have ? sb.ev_px[q] : 0; y_ = have ? sb.ev_py[q] : 0;
+        };
+        if (e < e1) load_events(e, node, ag, type_l, px_l, py_l);
+        while (e < e1) {
+            const bool have = e + lane < e1;
             // an event is ready when its agent has decided past it; the batch is the ready PREFIX (node order)
-            const bool ready = have && lds_ld64(&s_prog[ag]) > node;
+            // (relaxed, here and below: what the owners hand over is in LDS, which takes a wave's operations in the order they were
+            // issued -- an acquire would make this wave wait for its own stores to HBM as well)
+            const bool ready = have && __hip_atomic_load(&s_prog[MANY ? ag % n_ow : ag], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > node;
+            __asm__ volatile("" ::: "memory");
             const unsigned long long rm = __ballot(ready);
             const int k = rm == ~0ull ? 64 : (int)__builtin_ctzll(~rm);
             if (k == 0) {
@@ -1249,12 +1287,43 @@ qs_slam_chain_free_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuc
                 continue;
             }
             idle = 0;
+            if (e + k < e1) load_events(e + k, node_n, ag_n, type_n, px_n, py_n);
+#ifdef QS_FREE_PROF
+            const unsigned long long tp0 = __builtin_amdgcn_s_memtime();
+#endif
             const bool inw = lane < k;
             const int type = inw ? type_l : 0;
             const double px = inw ? px_l : 0, py = inw ? py_l : 0;
             // ---- every agent of the batch: its drift along its events, its decisions that fall into the batch ----
             double dx = 0, dy = 0, cdx = 0, cdy = 0;
             long long midx = LL_MAX;
+            if (MANY) {
+                // a lane per event; an agent with several events in the batch has them handled one per round, in node order
+                bool todo = inw;
+                while (__ballot(todo)) {
+                    if (todo) atomicMin(&c_tag[ag], (unsigned int)lane);
+                    __asm__ volatile("" ::: "memory");
+                    if (todo && __hip_atomic_load(&c_tag[ag], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == (unsigned int)lane) {
+                        const unsigned int dc = s_cons[ag];
+                        const unsigned int dp = __hip_atomic_load(&s_push[ag], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        dx = c_ddx[ag]; dy = c_ddy[ag];                              // matched / stored at the pose BEFORE the closure (:288, :308)
+                        __asm__ volatile("" ::: "memory");
+                        const unsigned int sl = dc % RD;
+                        if (dc != dp && q_idx[ag][sl] == node) {                     // (else the agent's next decision is about a later event)
+                            midx = q_midx[ag][sl]; cdx = q_cdx[ag][sl]; cdy = q_cdy[ag][sl];
+                            const double ndx = dx + cdx, ndy = dy + cdy;             // drift_correction[agent] += ...  :911-914
+                            const unsigned int apos = c_apos[ag];
+                            sb.acl_node[apos] = node; sb.acl_dx[apos] = ndx; sb.acl_dy[apos] = ndy;
+                            c_ddx[ag] = ndx; c_ddy[ag] = ndy; c_apos[ag] = apos + 1;
+                            __asm__ volatile("" ::: "memory");
+                            __hip_atomic_store(&s_cons[ag], dc + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                        c_tag[ag] = 0xffffffffu;
+                        todo = false;
+                    }
+                    __asm__ volatile("" ::: "memory");
+                }
+            } else
             for (unsigned long long rem = __ballot(inw); rem;) {
                 const int ld = __ffsll((long long)rem) - 1;
                 const int aa = __builtin_amdgcn_readlane(ag, ld);
@@ -1262,11 +1331,12 @@ qs_slam_chain_free_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuc
                 rem &= ~La;
                 double cur_dx = c_ddx[aa], cur_dy = c_ddy[aa];
                 unsigned int dc = s_cons[aa];
-                const unsigned int dp = lds_ld32(&s_push[aa]);
+                const unsigned int dp = __hip_atomic_load(&s_push[aa], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __asm__ volatile("" ::: "memory");
                 unsigned int apos = c_apos[aa];
                 unsigned long long left = La;                                        // lanes of aa not yet given their drift
                 while (dc != dp) {
-                    const unsigned int sl = dc % FR_RING;
+                    const unsigned int sl = dc % RD;
                     const long long qi = q_idx[aa][sl];
                     const unsigned long long lm = La & __ballot(node == qi);
                     if (!lm) break;                                                  // the agent's next decision is about a later event
@@ -1282,8 +1352,13 @@ qs_slam_chain_free_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuc
                     dc++;
                 }
                 if ((left >> lane) & 1) { dx = cur_dx; dy = cur_dy; }
-                if (lane == ld) { c_ddx[aa] = cur_dx; c_ddy[aa] = cur_dy; c_apos[aa] = apos; lds_st32(&s_cons[aa], dc); }
+                __asm__ volatile("" ::: "memory");
+                if (lane == ld) { c_ddx[aa] = cur_dx; c_ddy[aa] = cur_dy; c_apos[aa] = apos; __hip_atomic_store(&s_cons[aa], dc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
             }
+#ifdef QS_FREE_PROF
+            const unsigned long long tp1 = __builtin_amdgcn_s_memtime();
+            pf_agents += tp1 - tp0;
+#endif
             const double x = raw_pose ? px : px + dx, y = raw_pose ? py : py + dy;   // rx += cdx, ry += cdy  :856-857
             // ---- closure records, in node order  (:317) ----
             const bool closes = inw && midx != LL_MAX;
@@ -1303,13 +1378,17 @@ qs_slam_chain_free_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuc
             // ---- everything above complete, then the frontier moves ----
             // (workgroup scope: the readers are waves of this workgroup, on this CU; what is needed is that the stores are done)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            const long long next_node = (k < 64 && e + k < e1) ? rl64(node, k < 63 ? k : 63) : (e + k < e1 ? sb.ev_node[e + k] : LL_MAX);
+            const long long next_node = e + k < e1 ? rl64(node_n, 0) : LL_MAX;
             if (lane == 0) {
                 s_nmisc = n_misc; s_nlms = n_lms;
                 lds_st64(&s_frontier, next_node == LL_MAX ? LL_MAX : next_node - 1);
             }
             e += k;
+            node = node_n; ag = ag_n; type_l = type_n; px_l = px_n; py_l = py_n;
             st_batches++;
+#ifdef QS_FREE_PROF
+            pf_insert += __builtin_amdgcn_s_memtime() - tp1;
+#endif
         }
         if (lane == 0) {
             atomicAdd(&counters[QS_CNT_CLOSURES], (unsigned long long)(n_cls - G.n_cls));
@@ -1317,6 +1396,7 @@ qs_slam_chain_free_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuc
             atomicAdd(&counters[QS_CNT_SLAM_WINDOWS], st_batches);
 #ifdef QS_FREE_PROF
             atomicAdd(&counters[QS_CNT_SLAM_CYC_C], pf_idle);
+            atomicAdd(&counters[QS_CNT_EKF_WRAP_CLAMP], pf_agents); atomicAdd(&counters[QS_CNT_SLAM_MISC_ITERS], pf_insert);
 #endif
             atomicAdd(&counters[QS_CNT_SLAM_CYCLES], __builtin_amdgcn_s_memtime() - t0_cyc);
             atomicAdd(&counters[QS_CNT_SLAM_REALTIME], __builtin_amdgcn_s_memrealtime() - t0_real);
@@ -1421,12 +1501,15 @@ hipError_t qs_launch_slam(qs_ctx *c, size_t n, bool raw_pose)
                            c->bots_per_graph, c->cfg.max_agent, c->win, c->cfg.min_poses_between, c->r2_threshold,                          \
                            c->cfg.closure_correction, c->d_drift, c->d_last_closure, c->d_counters, raw_pose ? 1 : 0, c->d_flags + 1)
     const bool one = c->bots_per_graph <= CH_AGW;
-    // QS_CHAIN_MODE=window: the per-window kernel also for graphs of at most CH_AGW agents (default: the free-running form)
+    // QS_CHAIN_MODE=window: the per-window kernel (default: the free-running form)
     static const bool free_mode = [] { const char *e = getenv("QS_CHAIN_MODE"); return !(e && strcmp(e, "window") == 0); }();
-#define FR_LAUNCH(DENSE_) hipLaunchKernelGGL((qs_slam_chain_free_kernel<DENSE_>), dim3(G), dim3(CH_THREADS), 0, c->stream, c->d_graphs, sb, c->bg, \
+#define FR_LAUNCH(MANY_, DENSE_) hipLaunchKernelGGL((qs_slam_chain_free_kernel<MANY_, DENSE_>), dim3(G), dim3(CH_THREADS), 0, c->stream, c->d_graphs, sb, c->bg, \
                            c->bots_per_graph, c->cfg.max_agent, c->cfg.min_poses_between, c->r2_threshold,                                  \
                            c->cfg.closure_correction, c->d_drift, c->d_last_closure, c->d_counters, raw_pose ? 1 : 0, c->d_flags + 1)
-    if (one && free_mode) { if (c->pile_mode) FR_LAUNCH(true); else FR_LAUNCH(false); }
+    if (free_mode) {
+        if (one) { if (c->pile_mode) FR_LAUNCH(false, true); else FR_LAUNCH(false, false); }
+        else { if (c->pile_mode) FR_LAUNCH(true, true); else FR_LAUNCH(true, false); }
+    }
     else if (c->pile_mode) { if (one) CH_LAUNCH(true, true); else CH_LAUNCH(false, true); }
     else { if (one) CH_LAUNCH(true, false); else CH_LAUNCH(false, false); }
 #undef FR_LAUNCH
