@@ -984,6 +984,9 @@ __device__ inline long long free_query(const QsGraphDev *Gp, QsNodeG g_nodes, Qs
     bool dense = false;
     while (__ballot(node != 0)) {
         if (DENSE && rounds++ == dense_after) { dense = true; break; }
+#if defined(QS_FREE_PROF) && QS_FREE_PROF == 2
+        st_misc++;                                                       // (profile build: node rounds)
+#endif
         long long id = LL_MAX, lastid = LL_MAX;
         double nx = 0, ny = 0;
         unsigned int nxt = 0;
@@ -1070,11 +1073,7 @@ __device__ inline void lds_st64(long long *p, long long v) { __hip_atomic_store(
 __device__ inline unsigned int lds_ld32(const unsigned int *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ inline void lds_st32(unsigned int *p, unsigned int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
-// MANY: the graph has more agents than owner waves (up to 255 bots in ONE PoseGraphSLAM).  Owner wave w then runs the agents
-// a = w - 1 (mod n_ow), their events in node order: lane j keeps the state of agent (w - 1) + n_ow j; the decision rings are per
-// agent and short (an agent closes at most once in MIN_POSES_BETWEEN nodes), the progress word is the owner's.
-#define FR_RING_MANY 4
-template <bool MANY, bool DENSE>
+template <bool DENSE>
 __global__ void __launch_bounds__(CH_THREADS)
 qs_slam_chain_free_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGeom bg, int bots_per_graph,
                           int max_agent, int min_between, double r2thr, double corr,
@@ -1086,8 +1085,8 @@ qs_slam_chain_free_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuc
     const int bot0 = g * bots_per_graph + 1;
     const int nb = min(bots_per_graph, max_agent - bot0 + 1);
     const int n_ow = min(CH_AGW, nb);               // owner waves in use
-    constexpr int NA = MANY ? QS_MAX_AGENT + 1 : CH_AGW;     // agents a graph of this instantiation can have
-    constexpr int RD = MANY ? FR_RING_MANY : FR_RING;        // decisions an agent can be ahead of the committer
+    constexpr int NA = CH_AGW;                      // (graphs with more agents: qs_slam_chain_dyn_kernel)
+    constexpr int RD = FR_RING;                     // decisions an agent can be ahead of the committer
 
     // An owner hands the committer its DECISIONS only -- (closing node, matched landmark, correction), in the agent's order, in a
     // ring of RD slots -- and how far it has decided (s_prog).  Everything else about an event follows from those: the
@@ -1102,12 +1101,10 @@ qs_slam_chain_free_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuc
     // committer's own: every agent's drift as of the events it has passed, and where the agent's next closure record goes
     __shared__ double c_ddx[NA], c_ddy[NA];
     __shared__ unsigned int c_apos[NA];
-    __shared__ unsigned int c_tag[MANY ? NA : 1];   // MANY: the batch's first event of an agent that is still to be handled (a lane), else ~0
 
     const unsigned int e0 = sb.ev_base[g], e1 = sb.ev_base[g + 1];
     for (int t = tid; t < NA; t += CH_THREADS) {
         s_push[t] = 0; s_cons[t] = 0;
-        if (MANY) c_tag[t] = 0xffffffffu;
         if (t < nb) { c_ddx[t] = drift[2 * (bot0 + t)]; c_ddy[t] = drift[2 * (bot0 + t) + 1]; c_apos[t] = sb.agent_ev[bot0 + t]; }
     }
     if (tid < CH_AGW) s_prog[tid] = tid < n_ow ? (e0 < e1 ? sb.ev_node[e0] : LL_MAX) : LL_MAX;
@@ -1115,15 +1112,15 @@ qs_slam_chain_free_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuc
     __syncthreads();
 
     if (wave >= 1 && wave <= n_ow) {
-        // =================================== owner of agent wave - 1 (MANY: of the agents wave - 1 mod n_ow) ===================================
+        // =================================== owner of agent wave - 1 ===================================
         __builtin_amdgcn_s_setprio(3);             // the decisions are the critical path
         const int a = wave - 1;
-        // ONE agent: its state in every lane.  MANY: lane j keeps agent a + n_ow j (the authoritative copy; nothing else writes it)
-        const int my_agent = MANY ? a + n_ow * lane : a;
+        // its agent's state, in every lane (the authoritative copy; nothing else writes it)
+        const int my_agent = a;
         const bool my_valid = my_agent < nb;
         double c_dx = my_valid ? drift[2 * (bot0 + my_agent)] : 0, c_dy = my_valid ? drift[2 * (bot0 + my_agent) + 1] : 0;
         long long c_last = my_valid ? last_closure[bot0 + my_agent] : 0;
-        unsigned int pushed = 0, cons_c = 0;       // (MANY: of the lane's agent)
+        unsigned int pushed = 0, cons_c = 0;
         const QsNodeG g_nodes = (QsNodeG)Gp->nodes;
         const QsU32G g_next = (QsU32G)Gp->nd_next;
         unsigned long long st_misc = 0, st_wait = 0;
@@ -1153,13 +1150,11 @@ qs_slam_chain_free_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuc
             const long long idx = idx_n, next_first = nf_n;
             const double px = px_n, py = py_n;
             if (q0 + QS_WAVE < e1) load_chunk(q0 + QS_WAVE, ag_n, idx_n, type_n, px_n, py_n, nf_n);
-            const unsigned long long own = __ballot(ag >= 0 && (MANY ? ag % n_ow : ag) == a);
-            const int st_lane = MANY ? (ag >= 0 ? ag / n_ow : 0) : 0;               // the lane that keeps the event's agent's state
+            const unsigned long long own = __ballot(ag == a);
             unsigned long long done = 0;                                            // own lanes decided so far
             // the events that may close a loop (:304: their agent is past its cool-down); the ones before the first need no decision
             auto eligible = [&]() -> unsigned long long {
-                const long long last_ev = MANY ? __shfl(c_last, st_lane) : c_last;
-                return own & ~done & __ballot(idx - last_ev >= min_between);
+                return own & ~done & __ballot(idx - c_last >= min_between);
             };
             unsigned long long elig = eligible();
             while (elig) {
@@ -1167,10 +1162,9 @@ qs_slam_chain_free_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuc
                 // the acquire that orders the node loads after it comes with the query)
                 const long long fr0 = __hip_atomic_load(&s_frontier, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 const int f = __ffsll((long long)elig) - 1;
-                const int qa = MANY ? __builtin_amdgcn_readlane(ag, f) : a;
-                const int ql = MANY ? qa / n_ow : 0;                                // the lane that keeps agent qa's state
+                const int qa = a;
                 const long long qidx = rl64(idx, f);
-                const double odx = MANY ? rlf64(c_dx, ql) : c_dx, ody = MANY ? rlf64(c_dy, ql) : c_dy;
+                const double odx = c_dx, ody = c_dy;
                 const double spx = rlf64(px, f), spy = rlf64(py, f);
                 const double qx = raw_pose ? spx : spx + odx, qy = raw_pose ? spy : spy + ody;   // rx += cdx  :856-857
                 const int qtype = __builtin_amdgcn_readlane(type, f);
@@ -1198,8 +1192,7 @@ qs_slam_chain_free_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuc
                     const double ex = wx - qx, ey = wy - qy;                        // :311-312
                     const double cdx = ex * corr, cdy = ey * corr;                  // :314-315
                     // the agent's decision ring: a slot must be free
-                    unsigned int pq = MANY ? (unsigned int)__builtin_amdgcn_readlane((int)pushed, ql) : pushed;
-                    unsigned int cq = MANY ? (unsigned int)__builtin_amdgcn_readlane((int)cons_c, ql) : cons_c;
+                    unsigned int pq = pushed, cq = cons_c;
                     if (pq - cq >= (unsigned int)RD) {                              // looks full
                         cq = lds_ld32(&s_cons[qa]);
                         if (pq - cq >= (unsigned int)RD) {
@@ -1217,7 +1210,7 @@ qs_slam_chain_free_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuc
                         const unsigned int sl = pq % RD;
                         q_idx[qa][sl] = qidx; q_midx[qa][sl] = gbest; q_cdx[qa][sl] = cdx; q_cdy[qa][sl] = cdy;
                     }
-                    if (!MANY || lane == ql) {
+                    {
                         c_dx += cdx; c_dy += cdy; c_last = qidx;                    // :911-914, :318
                         pushed = pq + 1; cons_c = cq;
                     }
@@ -1232,7 +1225,7 @@ qs_slam_chain_free_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuc
             publish_prog(next_first);
         }
         publish_prog(LL_MAX);
-        if (my_valid && (MANY || lane == 0)) {
+        if (my_valid && lane == 0) {
             drift[2 * (bot0 + my_agent)] = c_dx; drift[2 * (bot0 + my_agent) + 1] = c_dy; last_closure[bot0 + my_agent] = c_last;
         }
         if (lane == 0) {
@@ -1274,7 +1267,7 @@ qs_slam_chain_free_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuc
             // an event is ready when its agent has decided past it; the batch is the ready PREFIX (node order)
             // (relaxed, here and below: what the owners hand over is in LDS, which takes a wave's operations in the order they were
             // issued -- an acquire would make this wave wait for its own stores to HBM as well)
-            const bool ready = have && __hip_atomic_load(&s_prog[MANY ? ag % n_ow : ag], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > node;
+            const bool ready = have && __hip_atomic_load(&s_prog[ag], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > node;
             __asm__ volatile("" ::: "memory");
             const unsigned long long rm = __ballot(ready);
             const int k = rm == ~0ull ? 64 : (int)__builtin_ctzll(~rm);
@@ -1297,33 +1290,6 @@ qs_slam_chain_free_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuc
             // ---- every agent of the batch: its drift along its events, its decisions that fall into the batch ----
             double dx = 0, dy = 0, cdx = 0, cdy = 0;
             long long midx = LL_MAX;
-            if (MANY) {
-                // a lane per event; an agent with several events in the batch has them handled one per round, in node order
-                bool todo = inw;
-                while (__ballot(todo)) {
-                    if (todo) atomicMin(&c_tag[ag], (unsigned int)lane);
-                    __asm__ volatile("" ::: "memory");
-                    if (todo && __hip_atomic_load(&c_tag[ag], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == (unsigned int)lane) {
-                        const unsigned int dc = s_cons[ag];
-                        const unsigned int dp = __hip_atomic_load(&s_push[ag], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        dx = c_ddx[ag]; dy = c_ddy[ag];                              // matched / stored at the pose BEFORE the closure (:288, :308)
-                        __asm__ volatile("" ::: "memory");
-                        const unsigned int sl = dc % RD;
-                        if (dc != dp && q_idx[ag][sl] == node) {                     // (else the agent's next decision is about a later event)
-                            midx = q_midx[ag][sl]; cdx = q_cdx[ag][sl]; cdy = q_cdy[ag][sl];
-                            const double ndx = dx + cdx, ndy = dy + cdy;             // drift_correction[agent] += ...  :911-914
-                            const unsigned int apos = c_apos[ag];
-                            sb.acl_node[apos] = node; sb.acl_dx[apos] = ndx; sb.acl_dy[apos] = ndy;
-                            c_ddx[ag] = ndx; c_ddy[ag] = ndy; c_apos[ag] = apos + 1;
-                            __asm__ volatile("" ::: "memory");
-                            __hip_atomic_store(&s_cons[ag], dc + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        }
-                        c_tag[ag] = 0xffffffffu;
-                        todo = false;
-                    }
-                    __asm__ volatile("" ::: "memory");
-                }
-            } else
             for (unsigned long long rem = __ballot(inw); rem;) {
                 const int ld = __ffsll((long long)rem) - 1;
                 const int aa = __builtin_amdgcn_readlane(ag, ld);
@@ -1396,7 +1362,7 @@ qs_slam_chain_free_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuc
             atomicAdd(&counters[QS_CNT_SLAM_WINDOWS], st_batches);
 #ifdef QS_FREE_PROF
             atomicAdd(&counters[QS_CNT_SLAM_CYC_C], pf_idle);
-            atomicAdd(&counters[QS_CNT_EKF_WRAP_CLAMP], pf_agents); atomicAdd(&counters[QS_CNT_SLAM_MISC_ITERS], pf_insert);
+            atomicAdd(&counters[QS_CNT_EKF_WRAP_CLAMP], pf_agents); if (QS_FREE_PROF != 2) atomicAdd(&counters[QS_CNT_SLAM_MISC_ITERS], pf_insert);
 #endif
             atomicAdd(&counters[QS_CNT_SLAM_CYCLES], __builtin_amdgcn_s_memtime() - t0_cyc);
             atomicAdd(&counters[QS_CNT_SLAM_REALTIME], __builtin_amdgcn_s_memrealtime() - t0_real);
@@ -1406,6 +1372,334 @@ qs_slam_chain_free_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuc
         }
         for (int t = lane; t < nb; t += QS_WAVE) sb.acl_cnt[bot0 + t] = c_apos[t] - sb.agent_ev[bot0 + t];
     }
+}
+
+// ---- the free-running form for graphs with more agents than owner waves: events DEALT to the owners as they come free ----
+// (up to 255 bots in ONE PoseGraphSLAM, dual_bot_mapper.py:267-275.)  With agents tied to waves the slowest wave sets the pace
+// -- bucket chains differ in length from agent to agent --; here the 14 owner waves take the events off ONE counter, in node
+// order.  An agent's decisions still happen one after the other: its state (drift, last closure: :911-914, :318) lives in LDS
+// with a word saying up to which of its events it is decided, and whoever holds the agent's next event waits for that word.
+// Which event that is -- the previous event of the same agent -- is worked out by wave 0 (the dispatcher), ahead of the owners.
+// The committer is the one of qs_slam_chain_free_kernel; "ready" = below the oldest event any owner is working on.
+// Waits point at OLDER events only (the agent's previous event, the frontier at q - MIN_POSES_BETWEEN, a ring slot held by an
+// older decision of the agent; the dispatcher at events committed), so the oldest undecided event can always go on.
+#define DY_RING 1024            // dispatcher -> owners: per event, the node index of the agent's previous event
+#define DY_RD 4                 // decisions an agent can be ahead of the committer
+#define DY_OWNERS (CH_WAVES - 2)
+template <bool DENSE>
+__global__ void __launch_bounds__(CH_THREADS)
+qs_slam_chain_dyn_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGeom bg, int bots_per_graph,
+                         int max_agent, int min_between, double r2thr, double corr,
+                         double *__restrict__ drift, long long *__restrict__ last_closure,
+                         unsigned long long *__restrict__ counters, int raw_pose, unsigned int *__restrict__ pile_flag)
+{
+    const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    QsGraphDev *const Gp = graphs + g;
+    const int bot0 = g * bots_per_graph + 1;
+    const int nb = min(bots_per_graph, max_agent - bot0 + 1);
+    constexpr int NA = QS_MAX_AGENT + 1;
+    constexpr long long LL_MIN_ = -LL_MAX - 1;
+
+    __shared__ long long q_idx[NA][DY_RD], q_midx[NA][DY_RD];                   // decisions: closing node; matched landmark's node
+    __shared__ double q_cdx[NA][DY_RD], q_cdy[NA][DY_RD];                       // the closure's correction (:314-315)
+    __shared__ unsigned int s_push[NA], s_cons[NA];                             // decisions pushed by the owners / taken by the committer
+    __shared__ double a_dx[NA], a_dy[NA];                                       // the agent's drift and last closure as of ...
+    __shared__ long long a_last[NA], a_node[NA];                                // ... its event a_node (decided up to and including it)
+    __shared__ long long s_prog[CH_WAVES];        // the event an owner is working on (LL_MAX: none left): everything older than all of them is decided
+    __shared__ long long s_frontier, s_nmisc, s_nlms;
+    __shared__ unsigned int s_head, s_disp, s_comm;   // events handed out / prepared by the dispatcher / committed (counts from e0)
+    __shared__ long long d_ring[DY_RING], d_last[NA];
+    __shared__ unsigned int d_tag[NA];
+    __shared__ double c_ddx[NA], c_ddy[NA];       // committer: every agent's drift as of the events it has passed
+    __shared__ unsigned int c_apos[NA], c_tag[NA];
+
+    const unsigned int e0 = sb.ev_base[g], e1 = sb.ev_base[g + 1];
+    for (int t = tid; t < NA; t += CH_THREADS) {
+        s_push[t] = 0; s_cons[t] = 0; d_tag[t] = 0xffffffffu; c_tag[t] = 0xffffffffu; d_last[t] = LL_MIN_; a_node[t] = LL_MIN_;
+        if (t < nb) {
+            const double dx = drift[2 * (bot0 + t)], dy = drift[2 * (bot0 + t) + 1];
+            a_dx[t] = dx; a_dy[t] = dy; c_ddx[t] = dx; c_ddy[t] = dy;
+            a_last[t] = last_closure[bot0 + t]; c_apos[t] = sb.agent_ev[bot0 + t];
+        }
+    }
+    if (tid < CH_WAVES) s_prog[tid] = (tid >= 1 && tid <= DY_OWNERS && e0 < e1) ? sb.ev_node[e0] : LL_MAX;
+    if (tid == 0) { s_frontier = e0 < e1 ? sb.ev_node[e0] - 1 : LL_MAX; s_nmisc = Gp->n_misc; s_nlms = Gp->n_lms; s_head = 0; s_disp = 0; s_comm = 0; }
+    __syncthreads();
+#define LD_RLX(p) __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define ST_RLX(p, v) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define CBAR() __asm__ volatile("" ::: "memory")      // LDS takes a wave's operations in the order they were issued: keeping the compiler to it is all a hand-over needs
+
+    if (wave == 0) {
+        // =================================== the dispatcher ===================================
+        for (unsigned int d = e0; d < e1; d += QS_WAVE) {
+            const unsigned int r = d - e0;
+            // a ring slot is free once the event that had it is committed
+            FR_SPIN(r + QS_WAVE > DY_RING && LD_RLX(&s_comm) + DY_RING < r + QS_WAVE);
+            const unsigned int q = d + lane;
+            const bool have = q < e1;
+            const int ag = have ? (int)sb.ev_agent[q] : 0;
+            const long long node = have ? sb.ev_node[q] : LL_MAX;
+            long long prev = LL_MIN_;
+            bool todo = have;
+            while (__ballot(todo)) {          // an agent's events of this chunk one per round, in node order
+                if (todo) atomicMin(&d_tag[ag], (unsigned int)lane);
+                CBAR();
+                if (todo && LD_RLX(&d_tag[ag]) == (unsigned int)lane) { prev = d_last[ag]; d_last[ag] = node; d_tag[ag] = 0xffffffffu; todo = false; }
+                CBAR();
+            }
+            if (have) d_ring[(r + lane) % DY_RING] = prev;
+            CBAR();
+            if (lane == 0) ST_RLX(&s_disp, min(r + QS_WAVE, e1 - e0));
+        }
+    } else if (wave <= DY_OWNERS) {
+        // =================================== an owner ===================================
+        __builtin_amdgcn_s_setprio(3);             // the decisions are the critical path
+        const QsNodeG g_nodes = (QsNodeG)Gp->nodes;
+        const QsU32G g_next = (QsU32G)Gp->nd_next;
+        unsigned long long st_misc = 0, st_wait = 0;
+        // two chunks of the event list in registers, a lane per event: the one the owner's event is in and the one after it
+        unsigned int cb = 0xffffffffu, nbase = 0xffffffffu;
+        int ag_c = 0, type_c = 0, ag_n = 0, type_n = 0;
+        long long idx_c = LL_MAX, idx_n = LL_MAX;
+        double px_c = 0, py_c = 0, px_n = 0, py_n = 0;
+        auto load_chunk = [&](unsigned int q0, int &ag, long long &idx, int &type, double &px, double &py) {
+            const unsigned int q = q0 + lane;
+            const bool have = q < e1;
+            ag = have ? (int)sb.ev_agent[q] : 0;
+            idx = have ? sb.ev_node[q] : LL_MAX;
+            type = have ? (int)sb.ev_type[q] : 0;
+            px = have ? sb.ev_px[q] : 0; py = have ? sb.ev_py[q] : 0;
+        };
+#ifdef QS_FREE_PROF
+        unsigned long long pf_wait = 0, pf_query = 0, pf_prev = 0, pf_grab = 0, pf_total0 = __builtin_amdgcn_s_memtime();
+#endif
+        for (;;) {
+#ifdef QS_FREE_PROF
+            const unsigned long long tg_ = __builtin_amdgcn_s_memtime();
+#endif
+            unsigned int t = 0;
+            if (lane == 0) t = atomicAdd(&s_head, 1u);
+            const unsigned int r = (unsigned int)__builtin_amdgcn_readfirstlane((int)t);
+            if (r >= e1 - e0) break;
+            const unsigned int i = e0 + r;
+            const unsigned int cbase = e0 + (r & ~(unsigned int)(QS_WAVE - 1));
+            if (cbase != cb) {
+                if (cbase == nbase) { ag_c = ag_n; idx_c = idx_n; type_c = type_n; px_c = px_n; py_c = py_n; }
+                else load_chunk(cbase, ag_c, idx_c, type_c, px_c, py_c);
+                cb = cbase; nbase = cbase + QS_WAVE;
+                if (nbase < e1) load_chunk(nbase, ag_n, idx_n, type_n, px_n, py_n);
+            }
+            const int l = (int)(i - cb);
+            const int qa = __builtin_amdgcn_readlane(ag_c, l);
+            const long long qidx = rl64(idx_c, l);
+            if (lane == 0) ST_RLX(&s_prog[wave], qidx);
+            // the agent's previous event has to be decided
+#ifdef QS_FREE_PROF
+            const unsigned long long tv_ = __builtin_amdgcn_s_memtime();
+            pf_grab += tv_ - tg_;
+#endif
+            FR_SPIN(LD_RLX(&s_disp) <= r);
+            CBAR();
+            const long long prev = d_ring[r % DY_RING];
+            FR_SPIN(LD_RLX(&a_node[qa]) < prev);
+            CBAR();
+#ifdef QS_FREE_PROF
+            pf_prev += __builtin_amdgcn_s_memtime() - tv_;
+#endif
+            const long long last = a_last[qa];
+            if (qidx - last >= min_between) {                                       // :304
+                const double odx = a_dx[qa], ody = a_dy[qa];
+                const long long fr0 = LD_RLX(&s_frontier);
+                const double spx = rlf64(px_c, l), spy = rlf64(py_c, l);
+                const double qx = raw_pose ? spx : spx + odx, qy = raw_pose ? spy : spy + ody;   // rx += cdx  :856-857
+                const int qtype = __builtin_amdgcn_readlane(type_c, l);
+                const long long limit = qidx - (min_between > 1 ? min_between : 1);  // :300; a node never sees its own landmark (:288)
+                long long gbest; double wx, wy;
+#ifdef QS_FREE_PROF
+                const unsigned long long tq_ = __builtin_amdgcn_s_memtime();
+#endif
+                for (long long fr = fr0;; fr = lds_ld64(&s_frontier)) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");            // the index as of that frontier, not older
+                    const long long nm = s_nmisc, nl = DENSE ? s_nlms : 0;
+                    gbest = free_query<DENSE>(Gp, g_nodes, g_next, bg, qx, qy, qtype, fr < limit ? fr : limit, r2thr, nm, nl, lane, wx, wy, st_misc);
+                    if (gbest != LL_MAX || fr >= limit) break;                      // a match below the frontier is final; so is "none" once all are in
+                    st_wait++;
+                    FR_SPIN(lds_ld64(&s_frontier) < limit);
+                }
+#ifdef QS_FREE_PROF
+                pf_query += __builtin_amdgcn_s_memtime() - tq_;
+#endif
+                if (gbest != LL_MAX) {
+                    const double ex = wx - qx, ey = wy - qy;                        // :311-312
+                    const double cdx = ex * corr, cdy = ey * corr;                  // :314-315
+                    const unsigned int pq = s_push[qa];
+                    unsigned int cq = LD_RLX(&s_cons[qa]);
+                    if (pq - cq >= (unsigned int)DY_RD) {
+#ifdef QS_FREE_PROF
+                        const unsigned long long t_ = __builtin_amdgcn_s_memtime();
+#endif
+                        FR_SPIN(pq - (cq = LD_RLX(&s_cons[qa])) >= (unsigned int)DY_RD);
+#ifdef QS_FREE_PROF
+                        pf_wait += __builtin_amdgcn_s_memtime() - t_;
+#endif
+                    }
+                    CBAR();
+                    if (lane == 0) {
+                        const unsigned int sl = pq % DY_RD;
+                        q_idx[qa][sl] = qidx; q_midx[qa][sl] = gbest; q_cdx[qa][sl] = cdx; q_cdy[qa][sl] = cdy;
+                        a_dx[qa] = odx + cdx; a_dy[qa] = ody + cdy; a_last[qa] = qidx;      // :911-914, :318
+                    }
+                    CBAR();
+                    if (lane == 0) ST_RLX(&s_push[qa], pq + 1);
+                }
+            }
+            CBAR();
+            if (lane == 0) ST_RLX(&a_node[qa], qidx);
+        }
+        if (lane == 0) ST_RLX(&s_prog[wave], LL_MAX);
+        if (lane == 0) {
+            if (st_misc) atomicAdd(&counters[QS_CNT_SLAM_MISC_ITERS], st_misc);
+            if (st_wait) atomicAdd(&counters[QS_CNT_SLAM_ROUNDS], st_wait);
+#ifdef QS_FREE_PROF
+            if (wave == 1) { atomicAdd(&counters[QS_CNT_SLAM_CYC_A], QS_FREE_PROF == 2 ? pf_prev : pf_wait);
+                             atomicAdd(&counters[QS_CNT_SLAM_CYC_B], QS_FREE_PROF == 2 ? pf_grab : pf_query);
+                             atomicAdd(&counters[QS_CNT_SLAM_NODE_ITERS], __builtin_amdgcn_s_memtime() - pf_total0); }
+#endif
+        }
+    } else {
+        // =================================== the committer ===================================
+        const QsGraphDev G = *Gp;
+        long long n_lms = G.n_lms, n_misc = G.n_misc, n_cls = G.n_cls;
+        unsigned int pool = G.nodes_used;
+        bool pile = false;
+        unsigned long long st_batches = 0;
+        const unsigned long long t0_cyc = __builtin_amdgcn_s_memtime(), t0_real = __builtin_amdgcn_s_memrealtime();
+        unsigned int e = e0, idle = 0;
+#ifdef QS_FREE_PROF
+        unsigned long long pf_idle = 0, pf_agents = 0, pf_insert = 0;
+#endif
+        long long node = LL_MAX, node_n = LL_MAX;
+        int ag = 0, type_l = 0, ag_n = 0, type_n = 0;
+        double px_l = 0, py_l = 0, px_n = 0, py_n = 0;
+        auto load_events = [&](unsigned int from, long long &nd, int &a_, int &ty, double &x_, double &y_) {
+            const unsigned int q = from + lane;
+            const bool have = q < e1;
+            nd = have ? sb.ev_node[q] : LL_MAX;
+            a_ = have ? (int)sb.ev_agent[q] : 0;
+            ty = have ? (int)sb.ev_type[q] : 0;
+            x_ = have ? sb.ev_px[q] : 0; y_ = have ? sb.ev_py[q] : 0;
+        };
+        if (e < e1) load_events(e, node, ag, type_l, px_l, py_l);
+        while (e < e1) {
+            const bool have = e + lane < e1;
+            // the batch: the events older than everything an owner is still working on (a PREFIX of the list)
+            const long long mp = wave_min_nonneg_i64((lane >= 1 && lane <= DY_OWNERS) ? LD_RLX(&s_prog[lane]) : LL_MAX);
+            CBAR();
+            const unsigned long long rm = __ballot(have && node < mp);
+            const int k = rm == ~0ull ? 64 : (int)__builtin_ctzll(~rm);
+            if (k == 0) {
+                if (++idle > FR_SPIN_MAX) { if (lane == 0) atomicAdd(&counters[QS_CNT_SLAM_ROUNDS], 1ull << 40); break; }   // (never: see FR_SPIN)
+#ifdef QS_FREE_PROF
+                pf_idle++;
+#endif
+                __builtin_amdgcn_s_sleep(1);
+                continue;
+            }
+            idle = 0;
+            if (e + k < e1) load_events(e + k, node_n, ag_n, type_n, px_n, py_n);
+#ifdef QS_FREE_PROF
+            const unsigned long long tp0 = __builtin_amdgcn_s_memtime();
+#endif
+            const bool inw = lane < k;
+            const int type = inw ? type_l : 0;
+            const double px = inw ? px_l : 0, py = inw ? py_l : 0;
+            // ---- the agents' drifts along the batch, from their decisions: a lane per event; an agent with several events in the
+            // batch has them handled one per round, in node order ----
+            double dx = 0, dy = 0, cdx = 0, cdy = 0;
+            long long midx = LL_MAX;
+            bool todo = inw;
+            while (__ballot(todo)) {
+                if (todo) atomicMin(&c_tag[ag], (unsigned int)lane);
+                CBAR();
+                if (todo && LD_RLX(&c_tag[ag]) == (unsigned int)lane) {
+                    const unsigned int dc = s_cons[ag];
+                    const unsigned int dp = LD_RLX(&s_push[ag]);
+                    dx = c_ddx[ag]; dy = c_ddy[ag];                                  // matched / stored at the pose BEFORE the closure (:288, :308)
+                    CBAR();
+                    const unsigned int sl = dc % DY_RD;
+                    if (dc != dp && q_idx[ag][sl] == node) {                         // (else the agent's next decision is about a later event)
+                        midx = q_midx[ag][sl]; cdx = q_cdx[ag][sl]; cdy = q_cdy[ag][sl];
+                        const double ndx = dx + cdx, ndy = dy + cdy;                 // drift_correction[agent] += ...  :911-914
+                        const unsigned int apos = c_apos[ag];
+                        sb.acl_node[apos] = node; sb.acl_dx[apos] = ndx; sb.acl_dy[apos] = ndy;
+                        c_ddx[ag] = ndx; c_ddy[ag] = ndy; c_apos[ag] = apos + 1;
+                        CBAR();
+                        ST_RLX(&s_cons[ag], dc + 1);
+                    }
+                    c_tag[ag] = 0xffffffffu;
+                    todo = false;
+                }
+                CBAR();
+            }
+#ifdef QS_FREE_PROF
+            const unsigned long long tp1 = __builtin_amdgcn_s_memtime();
+            pf_agents += tp1 - tp0;
+#endif
+            const double x = raw_pose ? px : px + dx, y = raw_pose ? py : py + dy;   // rx += cdx, ry += cdy  :856-857
+            // ---- closure records, in node order  (:317) ----
+            const bool closes = inw && midx != LL_MAX;
+            const unsigned long long cmask = __ballot(closes);
+            if (closes) {
+                const long long slot = n_cls + __popcll(cmask & ((1ull << lane) - 1));
+                if (slot < G.cap_cls) {
+                    G.cl_lm_idx[slot] = midx; G.cl_node_idx[slot] = node; G.cl_dx[slot] = cdx; G.cl_dy[slot] = cdy;
+                    G.cl_agent[slot] = (unsigned char)(bot0 + ag);
+                }
+            }
+            n_cls += __popcll(cmask);
+            // ---- self.landmarks.append(...)  :288, and the bucket index ----
+            int cx, cy;
+            const long long kb = (inw && bucket_cell(x, y, type, bg, cx, cy)) ? bucket_key(type, cx, cy, bg) : -1;
+            chain_insert_lanes(G, inw, lane, node, kb, x, y, type, k, lane, n_lms, n_misc, pool, pile);
+            // ---- everything above complete, then the frontier moves ----
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            const long long next_node = e + k < e1 ? rl64(node_n, 0) : LL_MAX;
+            e += k;
+            if (lane == 0) {
+                s_nmisc = n_misc; s_nlms = n_lms;
+                lds_st64(&s_frontier, next_node == LL_MAX ? LL_MAX : next_node - 1);
+                ST_RLX(&s_comm, e - e0);
+            }
+            node = node_n; ag = ag_n; type_l = type_n; px_l = px_n; py_l = py_n;
+            st_batches++;
+#ifdef QS_FREE_PROF
+            pf_insert += __builtin_amdgcn_s_memtime() - tp1;
+#endif
+        }
+        if (lane == 0) {
+            atomicAdd(&counters[QS_CNT_CLOSURES], (unsigned long long)(n_cls - G.n_cls));
+            atomicAdd(&counters[QS_CNT_LANDMARKS], (unsigned long long)(n_lms - G.n_lms));
+            atomicAdd(&counters[QS_CNT_SLAM_WINDOWS], st_batches);
+#ifdef QS_FREE_PROF
+            atomicAdd(&counters[QS_CNT_SLAM_CYC_C], pf_idle);
+            atomicAdd(&counters[QS_CNT_EKF_WRAP_CLAMP], pf_agents); if (QS_FREE_PROF != 2) atomicAdd(&counters[QS_CNT_SLAM_MISC_ITERS], pf_insert);
+#endif
+            atomicAdd(&counters[QS_CNT_SLAM_CYCLES], __builtin_amdgcn_s_memtime() - t0_cyc);
+            atomicAdd(&counters[QS_CNT_SLAM_REALTIME], __builtin_amdgcn_s_memrealtime() - t0_real);
+            Gp->n_nodes = G.n_nodes + sb.acc_total[g];
+            Gp->n_cls = n_cls; Gp->n_lms = n_lms; Gp->n_misc = n_misc; Gp->nodes_used = pool;
+            if (pile && pile_flag) *pile_flag = 1u;
+        }
+        for (int t = lane; t < nb; t += QS_WAVE) sb.acl_cnt[bot0 + t] = c_apos[t] - sb.agent_ev[bot0 + t];
+    }
+    // the agents' states go back to where the next ingest finds them
+    __syncthreads();
+    for (int t = tid; t < nb; t += CH_THREADS) {
+        drift[2 * (bot0 + t)] = a_dx[t]; drift[2 * (bot0 + t) + 1] = a_dy[t]; last_closure[bot0 + t] = a_last[t];
+    }
+#undef LD_RLX
+#undef ST_RLX
+#undef CBAR
 }
 
 // ---- pose: rx, ry of every accepted record (dual_bot_mapper.py:855-857) ---------------------------
@@ -1503,13 +1797,17 @@ hipError_t qs_launch_slam(qs_ctx *c, size_t n, bool raw_pose)
     const bool one = c->bots_per_graph <= CH_AGW;
     // QS_CHAIN_MODE=window: the per-window kernel (default: the free-running form)
     static const bool free_mode = [] { const char *e = getenv("QS_CHAIN_MODE"); return !(e && strcmp(e, "window") == 0); }();
-#define FR_LAUNCH(MANY_, DENSE_) hipLaunchKernelGGL((qs_slam_chain_free_kernel<MANY_, DENSE_>), dim3(G), dim3(CH_THREADS), 0, c->stream, c->d_graphs, sb, c->bg, \
+#define FR_LAUNCH(DENSE_) hipLaunchKernelGGL((qs_slam_chain_free_kernel<DENSE_>), dim3(G), dim3(CH_THREADS), 0, c->stream, c->d_graphs, sb, c->bg, \
+                           c->bots_per_graph, c->cfg.max_agent, c->cfg.min_poses_between, c->r2_threshold,                                  \
+                           c->cfg.closure_correction, c->d_drift, c->d_last_closure, c->d_counters, raw_pose ? 1 : 0, c->d_flags + 1)
+#define DY_LAUNCH(DENSE_) hipLaunchKernelGGL((qs_slam_chain_dyn_kernel<DENSE_>), dim3(G), dim3(CH_THREADS), 0, c->stream, c->d_graphs, sb, c->bg, \
                            c->bots_per_graph, c->cfg.max_agent, c->cfg.min_poses_between, c->r2_threshold,                                  \
                            c->cfg.closure_correction, c->d_drift, c->d_last_closure, c->d_counters, raw_pose ? 1 : 0, c->d_flags + 1)
     if (free_mode) {
-        if (one) { if (c->pile_mode) FR_LAUNCH(false, true); else FR_LAUNCH(false, false); }
-        else { if (c->pile_mode) FR_LAUNCH(true, true); else FR_LAUNCH(true, false); }
+        if (one) { if (c->pile_mode) FR_LAUNCH(true); else FR_LAUNCH(false); }
+        else { if (c->pile_mode) DY_LAUNCH(true); else DY_LAUNCH(false); }
     }
+#undef DY_LAUNCH
     else if (c->pile_mode) { if (one) CH_LAUNCH(true, true); else CH_LAUNCH(false, true); }
     else { if (one) CH_LAUNCH(true, false); else CH_LAUNCH(false, false); }
 #undef FR_LAUNCH

@@ -15,4 +15,4 @@ else:
 for _ in range(2):
     m.reset(); m.ingest_device(d.data_ptr(),B,42,0,0,seq0=0); m.sync()
 c=m.counters()
-print(json.dumps({"batches":c["slam_windows"],"kernel_cyc":c["slam_cycles"],"owner0_total":c["slam_node_iters"],"owner0_wait_space":c["slam_cyc_prepare"],"owner0_query":c["slam_cyc_query"],"committer_idle_spins":c["slam_cyc_commit"],"committer_agents_cyc":c["ekf_wrap_clamp"],"committer_insert_cyc":c["slam_misc_iters"],"closures":c["closures"],"frontier_waits":c["slam_rounds"]}))
+print(json.dumps({"batches":c["slam_windows"],"kernel_cyc":c["slam_cycles"],"owner0_total":c["slam_node_iters"],"owner0_wait_space":c["slam_cyc_prepare"],"owner0_query":c["slam_cyc_query"],"committer_idle_spins":c["slam_cyc_commit"],"committer_agents_cyc":c["ekf_wrap_clamp"],"committer_insert_cyc":c["slam_misc_iters"],"owner_prev_wait":c["rebases"],"closures":c["closures"],"frontier_waits":c["slam_rounds"]}))
