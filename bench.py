@@ -384,9 +384,9 @@ def secondary_64_bots(pkg, replay, torch, dev, side, args, G, counts, bpg=2, ste
     for line in bad:
         print(f"PARITY MISMATCH (64 bots, {m.n_graphs} pose graphs): {line}", file=sys.stderr)
     n_graphs = m.n_graphs
+    free_running = m.chain_form() == "free"
     m.close()
     win = max(cnt["slam_windows"], 1)
-    free_running = (bpg or 64) <= 13 and os.environ.get("QS_CHAIN_MODE", "") != "window"
     return {"workload": f"configs[2]: 64 bots (own generator runs, seeds 42..105) in {n_graphs} pose graph{'s' if n_graphs > 1 else ''}, own room "
                         f"tiles, {G}x{G} grid, {B} packets/step, same stages",
             "pose_graphs_per_gpu": n_graphs, "bots_per_graph": bpg or 64,
@@ -586,10 +586,10 @@ def run_rank(args):
         "frac_counter": (ray_traffic / (ray_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (ray_traffic and ray_ms > 0) else None,
         "counter_source": f"replayed from profiles/{prof_round}/{prof_dir}/pmc_*.csv (rocprofv3 --pmc passes of this command), NOT measured in this run"
                           if ray_traffic else None}
-    # which form of the chain kernel ran (csrc/slam.hip): graphs of at most 13 agents take the free-running form -- one owner wave
-    # per agent, no per-window barrier -- unless QS_CHAIN_MODE=window; larger graphs the windowed form
+    # which form of the chain kernel ran (csrc/slam.hip; qs_chain_form): free-running -- owner waves decide, a committer wave inserts
+    # behind them, no per-window barrier -- or per-window (QS_CHAIN_AUTO picks it for streams whose queries mostly find nothing)
     agents_per_graph = bpg or max_agent
-    free_running = agents_per_graph <= 13 and os.environ.get("QS_CHAIN_MODE", "") != "window"
+    free_running = m.chain_form() == "free"
     if chain_ms >= ray_ms:
         dom_ms = chain_ms
         win = max(cnt["slam_windows"], 1)

@@ -117,6 +117,8 @@ SIGNATURES = {
     "qs_nn_search": (_i32, [_vp, _vp, _sz, _vp, _sz, _f64, _i32, _vp, _vp, _vp]),
     "qs_diag_mfma_f64_rate": (_i32, [_vp, C.POINTER(_f64)]),
     "qs_diag_latencies": (_i32, [_vp, _vp]),
+    "qs_set_chain_form": (_i32, [_vp, _i32]),
+    "qs_chain_form": (_i32, [_vp]),
     "qs_voxel_downsample": (_i32, [_vp, _vp, _sz, _f64, _vp, _sz, C.POINTER(_sz)]),
     "qs_frontier_cells": (_i32, [_vp, _vp, _sz, C.POINTER(_sz)]),
     "qs_frontier_members": (_i32, [_vp, _vp, _sz, C.POINTER(_sz)]),

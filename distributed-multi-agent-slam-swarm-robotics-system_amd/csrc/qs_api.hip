@@ -9,6 +9,7 @@
 #include "qs_internal.h"
 
 static thread_local std::string g_create_err;
+static void chain_stats_poll(qs_ctx *c, bool synced);
 static int flush_edge_rays(qs_ctx *c);      // exact-trig mode: rays waiting for libm end points (defined with the ingest path)
 #define FLUSHCHK(c) do { int rcf__ = flush_edge_rays(c); if (rcf__ != QS_OK) return rcf__; } while (0)
 
@@ -232,8 +233,12 @@ extern "C" int qs_create(const qs_config *cfg, qs_ctx **out)
     CREATE_CHK(hipMalloc((void **)&c->d_graph_batch, (size_t)c->n_graphs * 2 * sizeof(unsigned long long)));
     CREATE_CHK(hipMalloc((void **)&c->d_ekf, (size_t)nb * 44 * sizeof(double)));
     CREATE_CHK(hipMalloc((void **)&c->d_ekf_prev, (size_t)nb * 4 * sizeof(double)));
-    CREATE_CHK(hipMalloc((void **)&c->d_flags, 4 * sizeof(unsigned int)));
-    CREATE_CHK(hipMemset(c->d_flags, 0, 4 * sizeof(unsigned int)));
+    CREATE_CHK(hipMalloc((void **)&c->d_flags, QS_N_FLAGS * sizeof(unsigned int)));
+    CREATE_CHK(hipMemset(c->d_flags, 0, QS_N_FLAGS * sizeof(unsigned int)));
+    CREATE_CHK(hipHostMalloc((void **)&c->h_chain_stat, 8 * sizeof(unsigned int), hipHostMallocDefault));
+    memset(c->h_chain_stat, 0, 8 * sizeof(unsigned int));
+    CREATE_CHK(hipEventCreateWithFlags(&c->ev_chain_stat, hipEventDisableTiming));
+    if (const char *e = getenv("QS_CHAIN_MODE")) c->chain_form = strcmp(e, "window") == 0 ? QS_CHAIN_WINDOW : strcmp(e, "free") == 0 ? QS_CHAIN_FREE : QS_CHAIN_AUTO;
     CREATE_CHK(hipMalloc((void **)&c->d_graphs, (size_t)c->n_graphs * sizeof(QsGraphDev)));
     CREATE_CHK(hipMemset(c->d_graphs, 0, (size_t)c->n_graphs * sizeof(QsGraphDev)));
     c->h_graphs.assign(c->n_graphs, QsGraphDev{});
@@ -277,7 +282,7 @@ extern "C" int qs_destroy(qs_ctx *c)
     free_batch(c);
     hipFree(c->d_stamps); hipFree(c->d_counts); hipFree(c->d_counts_fused); hipFree(c->d_io_ws); hipFree(c->d_offset); hipFree(c->d_drift);
     hipFree(c->d_last_closure); hipFree(c->d_zone); hipFree(c->d_counters); hipFree(c->d_graph_batch);
-    hipFree(c->d_ekf); hipFree(c->d_ekf_prev); hipFree(c->d_ekf_ws); hipFree(c->d_graphs); hipFree(c->d_flags); hipFree(c->d_pkts); hipFree(c->d_lens);
+    hipFree(c->d_ekf); hipFree(c->d_ekf_prev); hipFree(c->d_ekf_ws); hipFree(c->d_graphs); hipFree(c->d_flags); if (c->h_chain_stat) hipHostFree(c->h_chain_stat); if (c->ev_chain_stat) hipEventDestroy(c->ev_chain_stat); hipFree(c->d_pkts); hipFree(c->d_lens);
     hipFree(c->d_time); hipFree(c->d_bin_ws); hipFree(c->d_frontier_ws);
     hipFree(c->d_edge);
     hipFree(c->d_dirty); hipFree(c->d_counts_sent); hipFree(c->d_sf_bitmaps); hipFree(c->d_sf_lists); hipFree(c->d_sf_counts); hipFree(c->d_sf_payload);
@@ -306,6 +311,20 @@ extern "C" int qs_set_stream(qs_ctx *c, void *hip_stream)
         c->own_stream = true;
     }
     return QS_OK;
+}
+
+extern "C" int qs_set_chain_form(qs_ctx *c, int form)
+{
+    ARGCHK(c, c != nullptr);
+    ARGCHK(c, form == QS_CHAIN_AUTO || form == QS_CHAIN_FREE || form == QS_CHAIN_WINDOW);
+    c->chain_form = form;
+    return QS_OK;
+}
+
+extern "C" int qs_chain_form(qs_ctx *c)
+{
+    if (!c) return QS_E_INVAL;
+    return c->chain_last_free ? QS_CHAIN_FREE : QS_CHAIN_WINDOW;
 }
 
 extern "C" int qs_sync(qs_ctx *c)
@@ -496,19 +515,45 @@ static int io_reserve(qs_ctx *c, size_t bytes);
 // call that reads or hands out the grid, the counters or the pose graphs; qs_sync; before a stamp rebase) and dropped by
 // qs_reset.  The same synchronisation brings the graphs' real landmark / closure counts (capacity planning starts from them,
 // not from "every record so far was a landmark") and the pile flag of the loop-closure chain.
+// Which form of the loop-closure chain suits the stream (slam.hip, qs_launch_slam).  The kernels keep running totals in four
+// device words; every ingest asks for a copy of them into pinned memory behind itself and looks, before it launches its own
+// chain, at whatever copy has landed by then -- nobody waits.  What the per-window form counts as a miss (a query that found
+// nothing) includes what the free-running form counts (a decision that had to wait for the frontier), so a stream that sends
+// the free-running form away (> 1/8) is not sent back by the per-window form (< 1/16).
+static void chain_stats_poll(qs_ctx *c, bool synced)
+{
+    if (!c->chain_stat_pending) return;
+    if (!synced && hipEventQuery(c->ev_chain_stat) != hipSuccess) { (void)hipGetLastError(); return; }
+    c->chain_stat_pending = false;
+    unsigned int *now = c->h_chain_stat, *seen = c->h_chain_stat + 4;
+    const uint64_t f_miss = now[0] - seen[0], f_hit = now[1] - seen[1], w_miss = now[2] - seen[2], w_hit = now[3] - seen[3];
+    if (!c->chain_windowed) { if (f_miss + f_hit >= 256 && f_miss * 8 > f_hit) c->chain_windowed = true; }
+    else if (w_miss + w_hit >= 256 && w_miss * 16 < w_hit) c->chain_windowed = false;
+    for (int i = 0; i < 4; i++) seen[i] = now[i];
+}
+static int chain_stats_request(qs_ctx *c)
+{
+    if (c->chain_stat_pending) return QS_OK;                 // (the copy in flight will do)
+    HIPCHK(c, hipMemcpyAsync(c->h_chain_stat, c->d_flags + QS_FLAG_CHAIN_MISS, 4 * sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev_chain_stat, c->stream));
+    c->chain_stat_pending = true;
+    return QS_OK;
+}
+
 static int flush_edge_rays(qs_ctx *c)
 {
-    if (!c->edge_maybe) return QS_OK;
-    unsigned int fl[4] = {0, 0, 0, 0};
+    if (!c->edge_maybe && !c->flags_maybe) return QS_OK;
+    unsigned int fl[QS_N_FLAGS] = {0};
     HIPCHK(c, hipMemcpyAsync(fl, c->d_flags, sizeof fl, hipMemcpyDeviceToHost, c->stream));
     std::vector<QsGraphDev> cur((size_t)c->n_graphs);
     HIPCHK(c, hipMemcpyAsync(cur.data(), c->d_graphs, cur.size() * sizeof(QsGraphDev), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->edge_maybe = false;
+    c->edge_maybe = false; c->flags_maybe = false;
     for (int g = 0; g < c->n_graphs; g++) { c->lms_upper[g] = cur[g].n_lms; c->cls_upper[g] = cur[g].n_cls; }
-    if (fl[1]) c->pile_mode = true;                      // a landmark pile has formed: the chain kernel's DENSE variant from now on
-    const unsigned int n_edge = fl[0] < QS_EDGE_CAP ? fl[0] : QS_EDGE_CAP;
-    c->edge_overflow_total += fl[2];
+    if (fl[QS_FLAG_PILE]) c->pile_mode = true;           // a landmark pile has formed: the chain kernel's DENSE variant from now on
+    chain_stats_poll(c, true);
+    const unsigned int n_edge = fl[QS_FLAG_EDGE_N] < QS_EDGE_CAP ? fl[QS_FLAG_EDGE_N] : QS_EDGE_CAP;
+    c->edge_overflow_total += fl[QS_FLAG_EDGE_OVF];
     if (n_edge == 0) return QS_OK;
     c->edge_rays_total += n_edge;
     std::vector<QsEdgeRec> recs(n_edge);
@@ -540,15 +585,11 @@ static int flush_edge_rays(qs_ctx *c)
     return QS_OK;
 }
 
-// at a point where the stream is synchronised anyway: has a landmark pile formed (slam.hip, DENSE)?
+// at a point where the host waits for the stream anyway: the chain's flags (pile, form statistics)
 static int read_pile_flag(qs_ctx *c)
 {
-    if (c->pile_mode) return QS_OK;
-    unsigned int f = 0;
-    HIPCHK(c, hipMemcpyAsync(&f, c->d_flags + 1, sizeof f, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (f) c->pile_mode = true;
-    return QS_OK;
+    c->flags_maybe = true;
+    return flush_edge_rays(c);
 }
 
 static int ingest_device(qs_ctx *c, const uint8_t *d_pkts, size_t n, size_t stride, const uint16_t *d_lens,
@@ -613,7 +654,9 @@ static int ingest_device(qs_ctx *c, const uint8_t *d_pkts, size_t n, size_t stri
                                                    : qs_launch_ekf_ingest(c, n, d_time, c->ekf_stream)); t.stop(); }
         HIPCHK(c, hipEventRecord(c->ev_ekf_done, c->ekf_stream));
     }
+    chain_stats_poll(c, false);
     { StageTimer t(c, QS_STAGE_SLAM); HIPCHK(c, qs_launch_slam(c, n)); t.stop(); }
+    { int rcs = chain_stats_request(c); if (rcs != QS_OK) return rcs; }
     {
         StageTimer t(c, QS_STAGE_RAYCAST);
         // auto (0): a handful of packets (the live UDP path: <= 20 per frame) is one direct kernel instead
@@ -625,6 +668,7 @@ static int ingest_device(qs_ctx *c, const uint8_t *d_pkts, size_t n, size_t stri
     }
     if (c->cfg.enable_ekf) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_ekf_done, 0));   // join
     if (c->b.edge) c->edge_maybe = true;                 // resolved at the next point the map is observed (flush_edge_rays)
+    c->flags_maybe = true;
     c->next_seq = seq0 + n * sstride;
     c->dirty_since_fuse = true;
     return QS_OK;
@@ -663,11 +707,7 @@ extern "C" int qs_ingest(qs_ctx *c, const uint8_t *pkts, size_t n, size_t stride
     if (rc != QS_OK) return rc;
     // this call waits for the GPU anyway (the caller's buffers are free when it returns): the waiting edge rays are resolved
     // now, and the graphs' real landmark / closure counts and the pile flag come along
-    if (c->cfg.exact_trig) { c->edge_maybe = true; return flush_edge_rays(c); }
-    std::vector<QsGraphDev> cur((size_t)c->n_graphs);
-    HIPCHK(c, hipMemcpyAsync(cur.data(), c->d_graphs, cur.size() * sizeof(QsGraphDev), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (int g = 0; g < c->n_graphs; g++) { c->lms_upper[g] = cur[g].n_lms; c->cls_upper[g] = cur[g].n_cls; }
+    if (c->cfg.exact_trig) c->edge_maybe = true;
     return read_pile_flag(c);
 }
 
@@ -949,7 +989,9 @@ extern "C" int qs_slam_add_poses(qs_ctx *c, const double *x, const double *y, co
     if (rc != QS_OK) return rc;
     std::vector<QsGraphDev> before(G), after(G);
     HIPCHK(c, hipMemcpyAsync(before.data(), c->d_graphs, (size_t)G * sizeof(QsGraphDev), hipMemcpyDeviceToHost, c->stream));
+    chain_stats_poll(c, false);
     HIPCHK(c, qs_launch_slam(c, n, true));
+    { int rcs = chain_stats_request(c); if (rcs != QS_OK) return rcs; }
     HIPCHK(c, hipMemcpyAsync(after.data(), c->d_graphs, (size_t)G * sizeof(QsGraphDev), hipMemcpyDeviceToHost, c->stream));
     std::vector<long long> node(n);
     HIPCHK(c, hipMemcpyAsync(node.data(), c->sb.node, n * sizeof(long long), hipMemcpyDeviceToHost, c->stream));

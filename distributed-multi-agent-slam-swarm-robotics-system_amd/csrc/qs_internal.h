@@ -96,6 +96,16 @@ __host__ __device__ inline size_t qs_dirty_word(int x, int y, int pitch) { retur
 __host__ __device__ inline unsigned int qs_dirty_mask(int x) { return 1u << ((x / QS_DIRTY_BLOCK_W) & 31); }
 
 // a ray left to the host (exact-trig mode): everything needed to cast it later, whatever has happened to its batch since
+// device words read by the host at synchronisation points (qs_ctx::d_flags; qs_reset clears the first four)
+enum { QS_FLAG_EDGE_N = 0,        // exact-trig mode: edge rays waiting for the host
+       QS_FLAG_PILE = 1,          // a landmark pile has formed (slam.hip, DENSE)
+       QS_FLAG_EDGE_OVF = 2,      // edge rays that found the waiting list full
+       // loop-closure chain, running totals (never cleared; the host looks at differences -- qs_api.hip, chain_stats_poll):
+       QS_FLAG_CHAIN_MISS = 4,    // free-running form: decisions that waited for the frontier ...
+       QS_FLAG_CHAIN_HIT = 5,     // ... and its closures
+       QS_FLAG_CHAINW_MISS = 6,   // per-window form: eligible queries that found nothing ...
+       QS_FLAG_CHAINW_HIT = 7,    // ... and its closures
+       QS_N_FLAGS = 8 };
 struct QsEdgeRec { double rx, ry, yaw; float d; unsigned int key_free; };     // key_free: stamp of its free cells ((ordinal << 1) | 0)
 #define QS_EDGE_CAP (1u << 18)
 
@@ -184,11 +194,17 @@ struct qs_ctx {
     void *d_ekf_ws = nullptr; size_t ekf_ws_bytes = 0;   // parallel-in-time EKF workspace (ekf_scan.hip)
 
     uint64_t next_seq = 0, epoch_base = 0, n_rebases = 0;
-    unsigned int *d_flags = nullptr;             // [0] edge rays waiting for the host (exact-trig mode), [1] a landmark pile has formed
-                                                 // (slam.hip, DENSE), [2] edge rays that found the list full, [3] spare
+    unsigned int *d_flags = nullptr;             // [QS_N_FLAGS] device words the host reads at synchronisation points (QS_FLAG_*)
     QsEdgeRec *d_edge = nullptr;                 // [QS_EDGE_CAP] the waiting rays
     bool edge_maybe = false;                     // an exact-trig ingest has run since the last flush: the list may hold rays
     bool pile_mode = false;                      // launch the chain kernel's DENSE variant
+    bool flags_maybe = false;                    // a loop-closure chain has run since the flags were read last
+    int chain_form = 0;                          // QS_CHAIN_AUTO / _FREE / _WINDOW (qs_set_chain_form)
+    bool chain_windowed = false;                 // QS_CHAIN_AUTO's present choice for graphs of few agents (slam.hip, qs_launch_slam)
+    bool chain_last_free = true;                 // the form the last launch used
+    unsigned int *h_chain_stat = nullptr;        // pinned: [0..3] the four running totals as copied last, [4..7] as consumed last
+    hipEvent_t ev_chain_stat = nullptr;          // ... complete when the copy has landed
+    bool chain_stat_pending = false;
     uint64_t edge_rays_total = 0;                // exact-trig mode: rays resolved on the host since the last reset
     uint64_t edge_overflow_total = 0;            //   ... and rays that found the list full (cast with the device's trig)
 

@@ -590,6 +590,7 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
         }
         if (lane == 0) {
             atomicAdd(&counters[QS_CNT_CLOSURES], (unsigned long long)(n_cls - n_cls0));
+            if (pile_flag) atomicAdd(pile_flag + QS_FLAG_CHAINW_HIT - QS_FLAG_PILE, (unsigned int)(n_cls - n_cls0));
             atomicAdd(&counters[QS_CNT_SLAM_WINDOWS], st_windows);
 #if !defined(QS_CHAIN_PROF) && !defined(QS_CHAIN_PROF2) && !defined(QS_CHAIN_PROF3)
             atomicAdd(&counters[QS_CNT_SLAM_CYC_A], st_a); atomicAdd(&counters[QS_CNT_SLAM_CYC_B], st_b);
@@ -667,6 +668,7 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
         const int own = (wave - 1) + n_ow * lane;  // (!ONE: the agents whose final state this wave writes back at the end)
         double c_dx = 0, c_dy = 0;
         long long c_last = 0;
+        unsigned int st_nomatch = 0;               // eligible queries that found nothing (what the free-running form would wait on)
         if (ONE) { c_dx = s_dx[0][wave - 1]; c_dy = s_dy[0][wave - 1]; c_last = s_lastc[0][wave - 1]; }     // one agent: every lane holds its state
         const QsNodeG g_nodes = (QsNodeG)Gp->nodes;
         const QsU32G g_next = (QsU32G)Gp->nd_next;
@@ -874,7 +876,7 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
                         if (lane == 0) { s_dx[par ^ 1][qa] = ndx; s_dy[par ^ 1][qa] = ndy; s_lastc[par ^ 1][qa] = qidx; }   // (after the carry-over above)
                         if (ownlane && W.v_a == qa) { nw_dx = ndx; nw_dy = ndy; nw_last = qidx; }
                     }
-                }
+                } else st_nomatch++;
 #ifdef QS_CHAIN_PROF
                 { const unsigned long long tq3 = __builtin_amdgcn_s_memtime(); pq_a += tq1 - tq0; pq_b += tq2 - tq1; pq_c += tq3 - tq2; }
 #endif
@@ -922,6 +924,7 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
             last_closure[bot0 + own] = s_lastc[par][own];
         }
         if (lane == 0) {
+            if (st_nomatch && pile_flag) atomicAdd(pile_flag + QS_FLAG_CHAINW_MISS - QS_FLAG_PILE, st_nomatch);
 #if defined(QS_CHAIN_STATS) && !defined(QS_CHAIN_PROF2)
             atomicAdd(&counters[QS_CNT_SLAM_ROUNDS], st_rounds);
             atomicAdd(&counters[QS_CNT_SLAM_NODE_ITERS], st_iters);
@@ -1230,7 +1233,7 @@ qs_slam_chain_free_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuc
         }
         if (lane == 0) {
             if (st_misc) atomicAdd(&counters[QS_CNT_SLAM_MISC_ITERS], st_misc);
-            if (st_wait) atomicAdd(&counters[QS_CNT_SLAM_ROUNDS], st_wait);
+            if (st_wait) { atomicAdd(&counters[QS_CNT_SLAM_ROUNDS], st_wait); if (pile_flag) atomicAdd(pile_flag + QS_FLAG_CHAIN_MISS - QS_FLAG_PILE, (unsigned int)st_wait); }
 #ifdef QS_FREE_PROF
             if (a == 0) { atomicAdd(&counters[QS_CNT_SLAM_CYC_A], pf_wait); atomicAdd(&counters[QS_CNT_SLAM_CYC_B], pf_query);
                           atomicAdd(&counters[QS_CNT_SLAM_NODE_ITERS], __builtin_amdgcn_s_memtime() - pf_total0); }
@@ -1358,6 +1361,7 @@ qs_slam_chain_free_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuc
         }
         if (lane == 0) {
             atomicAdd(&counters[QS_CNT_CLOSURES], (unsigned long long)(n_cls - G.n_cls));
+            if (pile_flag) atomicAdd(pile_flag + QS_FLAG_CHAIN_HIT - QS_FLAG_PILE, (unsigned int)(n_cls - G.n_cls));
             atomicAdd(&counters[QS_CNT_LANDMARKS], (unsigned long long)(n_lms - G.n_lms));
             atomicAdd(&counters[QS_CNT_SLAM_WINDOWS], st_batches);
 #ifdef QS_FREE_PROF
@@ -1559,7 +1563,7 @@ qs_slam_chain_dyn_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuck
         if (lane == 0) ST_RLX(&s_prog[wave], LL_MAX);
         if (lane == 0) {
             if (st_misc) atomicAdd(&counters[QS_CNT_SLAM_MISC_ITERS], st_misc);
-            if (st_wait) atomicAdd(&counters[QS_CNT_SLAM_ROUNDS], st_wait);
+            if (st_wait) { atomicAdd(&counters[QS_CNT_SLAM_ROUNDS], st_wait); if (pile_flag) atomicAdd(pile_flag + QS_FLAG_CHAIN_MISS - QS_FLAG_PILE, (unsigned int)st_wait); }
 #ifdef QS_FREE_PROF
             if (wave == 1) { atomicAdd(&counters[QS_CNT_SLAM_CYC_A], QS_FREE_PROF == 2 ? pf_prev : pf_wait);
                              atomicAdd(&counters[QS_CNT_SLAM_CYC_B], QS_FREE_PROF == 2 ? pf_grab : pf_query);
@@ -1678,6 +1682,7 @@ qs_slam_chain_dyn_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuck
         }
         if (lane == 0) {
             atomicAdd(&counters[QS_CNT_CLOSURES], (unsigned long long)(n_cls - G.n_cls));
+            if (pile_flag) atomicAdd(pile_flag + QS_FLAG_CHAIN_HIT - QS_FLAG_PILE, (unsigned int)(n_cls - G.n_cls));
             atomicAdd(&counters[QS_CNT_LANDMARKS], (unsigned long long)(n_lms - G.n_lms));
             atomicAdd(&counters[QS_CNT_SLAM_WINDOWS], st_batches);
 #ifdef QS_FREE_PROF
@@ -1793,16 +1798,21 @@ hipError_t qs_launch_slam(qs_ctx *c, size_t n, bool raw_pose)
     StageTimer t_chain(c, QS_STAGE_SLAM_CHAIN);
 #define CH_LAUNCH(ONE_, DENSE_) hipLaunchKernelGGL((qs_slam_chain_kernel<ONE_, DENSE_>), dim3(G), dim3(CH_THREADS), 0, c->stream, c->d_graphs, sb, c->bg, \
                            c->bots_per_graph, c->cfg.max_agent, c->win, c->cfg.min_poses_between, c->r2_threshold,                          \
-                           c->cfg.closure_correction, c->d_drift, c->d_last_closure, c->d_counters, raw_pose ? 1 : 0, c->d_flags + 1)
+                           c->cfg.closure_correction, c->d_drift, c->d_last_closure, c->d_counters, raw_pose ? 1 : 0, c->d_flags + QS_FLAG_PILE)
     const bool one = c->bots_per_graph <= CH_AGW;
-    // QS_CHAIN_MODE=window: the per-window kernel (default: the free-running form)
-    static const bool free_mode = [] { const char *e = getenv("QS_CHAIN_MODE"); return !(e && strcmp(e, "window") == 0); }();
+    // which form (qs_set_chain_form; QS_CHAIN_MODE at qs_create).  Graphs of up to CH_AGW agents, left to themselves: the
+    // free-running form until a batch had it wait for the frontier in more than 1 of 8 decisions -- a stream whose queries mostly
+    // find nothing makes every other decision wait for the committer, and the per-window kernel, which sees the newest landmarks
+    // in LDS, is the faster one there --, the per-window form until fewer than 1 in 16 of its queries come back empty
+    // (chain_stats_poll in qs_api.hip reads the counts, without waiting for anything).  Same results either way.
+    const bool free_mode = c->chain_form == QS_CHAIN_FREE || (c->chain_form == QS_CHAIN_AUTO && !(one && c->chain_windowed));
+    c->chain_last_free = free_mode;
 #define FR_LAUNCH(DENSE_) hipLaunchKernelGGL((qs_slam_chain_free_kernel<DENSE_>), dim3(G), dim3(CH_THREADS), 0, c->stream, c->d_graphs, sb, c->bg, \
                            c->bots_per_graph, c->cfg.max_agent, c->cfg.min_poses_between, c->r2_threshold,                                  \
-                           c->cfg.closure_correction, c->d_drift, c->d_last_closure, c->d_counters, raw_pose ? 1 : 0, c->d_flags + 1)
+                           c->cfg.closure_correction, c->d_drift, c->d_last_closure, c->d_counters, raw_pose ? 1 : 0, c->d_flags + QS_FLAG_PILE)
 #define DY_LAUNCH(DENSE_) hipLaunchKernelGGL((qs_slam_chain_dyn_kernel<DENSE_>), dim3(G), dim3(CH_THREADS), 0, c->stream, c->d_graphs, sb, c->bg, \
                            c->bots_per_graph, c->cfg.max_agent, c->cfg.min_poses_between, c->r2_threshold,                                  \
-                           c->cfg.closure_correction, c->d_drift, c->d_last_closure, c->d_counters, raw_pose ? 1 : 0, c->d_flags + 1)
+                           c->cfg.closure_correction, c->d_drift, c->d_last_closure, c->d_counters, raw_pose ? 1 : 0, c->d_flags + QS_FLAG_PILE)
     if (free_mode) {
         if (one) { if (c->pile_mode) FR_LAUNCH(true); else FR_LAUNCH(false); }
         else { if (c->pile_mode) DY_LAUNCH(true); else DY_LAUNCH(false); }

@@ -403,6 +403,17 @@ class QuasarMapper:
                   "qs_nn_search")
         return corr, d2, (float(ms[0]), float(ms[1]))
 
+    CHAIN_FORMS = {"auto": 0, "free": 1, "window": 2}
+
+    def set_chain_form(self, form):
+        """Which device form of the loop-closure chain runs: "auto" (default), "free" (free-running), "window" (one barrier
+        per window).  Same closures, landmarks and drifts either way (dual_bot_mapper.py:292-326)."""
+        self._chk(self._L.qs_set_chain_form(self._h, self.CHAIN_FORMS[form]), "qs_set_chain_form")
+
+    def chain_form(self):
+        """The form the last ingest used: "free" or "window"."""
+        return {1: "free", 2: "window"}[self._L.qs_chain_form(self._h)]
+
     def mfma_f64_rate(self):
         """Measured dense fp64 MFMA rate of this GPU in TFLOP/s (diagnostic)."""
         v = C.c_double()

@@ -1190,6 +1190,71 @@ def test_trig_edge_hunt_exact_mode(pkg):
           f"cells differing from the oracle with exact_trig=0: {flips_off}")
 
 
+def _chain_equal(m, o, n_graphs, nb):
+    for g in range(n_graphs):
+        idx, cc = m.closures(g); oi, oc = o.closures(g)
+        assert idx.shape == oi.shape and (idx == oi).all() and (len(oi) == 0 or np.abs(cc - oc).max() < 1e-9)
+        xy, ti = m.landmarks(g); oxy, oti = o.landmarks(g)
+        assert ti.shape == oti.shape and (ti == oti).all() and (len(oti) == 0 or np.abs(xy - oxy).max() < 1e-9)
+    for b in range(1, nb + 1):
+        assert np.allclose(m.drift(b), o.drift(b), rtol=0, atol=1e-9)
+
+
+@pytest.mark.parametrize("form", ["free", "window"])
+@pytest.mark.parametrize("workload", ["session_2_bots", "adversarial_2_bots", "20_bots_one_graph", "14_bots_two_graphs"])
+def test_both_chain_forms_equal_the_oracle(pkg, form, workload):
+    """dual_bot_mapper.py:292-326 has two device forms (csrc/slam.hip): free-running (owner waves decide, a committer inserts
+    behind them; graphs of more than 13 bots: events dealt to 14 owners) and one barrier per window.  QS_CHAIN_AUTO picks per
+    stream, so each form is pinned here on its own: same closures, landmarks, drifts and grid as the oracle, over batch cuts."""
+    replay = _replay(pkg)
+    session, _ = replay.telemetry_csv_to_packets()
+    nb, bpg = {"session_2_bots": (2, 0), "adversarial_2_bots": (2, 0), "20_bots_one_graph": (20, 0), "14_bots_two_graphs": (14, 7)}[workload]
+    if workload == "session_2_bots":
+        stream = replay.cycle_stream(session, 30000)
+    elif workload == "adversarial_2_bots":
+        stream = replay.adversarial_stream(30000, seed=5, lo=-6.0, hi=6.0)
+    else:
+        stream = replay.multi_bot_stream(session, nb, 30000, pitch=1.0, origin=(-8.0, -8.0), tiles_per_row=5)
+    o = orc.OracleMapper(512, 0.05, -12.8, -12.8, 0.0, max_agent=nb, bots_per_graph=bpg)
+    o.feed_stream(stream)
+    with pkg.QuasarMapper(512, 0.05, -12.8, -12.8, max_agent=nb, bots_per_graph=bpg) as m:
+        m.set_chain_form(form)
+        for lo, hi in ((0, 7000), (7000, 7001), (7001, 19000), (19000, 30000)):
+            m.ingest_array(stream[lo:hi])
+            assert m.chain_form() == form
+        assert (m.grid_i8() == o.grid).all()
+        _chain_equal(m, o, m.n_graphs, nb)
+        assert m.counters()["slam_rounds"] < (1 << 40)              # no wait of the free-running form ran out of patience
+
+
+def test_chain_form_follows_the_stream(pkg):
+    """QS_CHAIN_AUTO: the free-running form while its decisions rarely wait for the frontier (the 2-bot session: 99.8 % of the
+    queries find a match in what the index already holds), the per-window form once a batch's decisions waited in more than 1 of
+    8 cases (uniform-random poses: every other query finds nothing and has to wait for the committer), and back.  The choice
+    survives qs_reset; results equal the oracle's throughout."""
+    replay = _replay(pkg)
+    session, _ = replay.telemetry_csv_to_packets()
+    calm = replay.cycle_stream(session, 20000)
+    wild = replay.adversarial_stream(20000, seed=9, lo=-12.0, hi=12.0)
+    o = orc.OracleMapper(512, 0.05, -12.8, -12.8, 0.0)
+    with pkg.QuasarMapper(512, 0.05, -12.8, -12.8) as m:
+        forms = []
+        for part in (calm, wild, wild, calm, calm):
+            m.ingest_array(part); o.feed_stream(part)
+            forms.append(m.chain_form())
+        assert forms[0] == "free" and forms[1] == "free"            # the wild batch itself still ran free; its counts arrive after it
+        assert forms[2] == "window"
+        assert forms[4] == "free"
+        assert (m.grid_i8() == o.grid).all()
+        _chain_equal(m, o, 1, 2)
+        m.reset()
+        m.ingest_array(wild)
+        assert m.chain_form() == "free"                             # (the calm batches chose it)
+        m.reset()
+        m.ingest_array(wild[:5000])
+        assert m.chain_form() == "window"                           # kept over the reset: it describes the stream
+
+
 def pkg_replay_adversarial(pkg, n, seed):
     import importlib
     replay = importlib.import_module(pkg.__name__ + ".replay")

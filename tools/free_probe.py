@@ -6,7 +6,10 @@ pkg=importlib.import_module(PKG); replay=importlib.import_module(PKG+".replay")
 B=1<<20
 session,_=replay.telemetry_csv_to_packets()
 wl=sys.argv[1] if len(sys.argv)>1 else "c1"
-if wl=="c1":
+if wl=="adv":
+    d=torch.from_numpy(replay.adversarial_stream(B)).cuda()
+    m=pkg.QuasarMapper(4096,0.05,-102.4,-102.4,max_agent=2,exact_trig=False)
+elif wl=="c1":
     d=torch.from_numpy(replay.cycle_stream(session,B)).cuda()
     m=pkg.QuasarMapper(4096,0.05,-102.4,-102.4,max_agent=2,exact_trig=False)
 else:

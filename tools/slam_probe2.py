@@ -12,7 +12,10 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else (1 << 20)
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 session, _ = replay.telemetry_csv_to_packets()
 wl = sys.argv[3] if len(sys.argv) > 3 else "c1"           # c1: 2 bots; one64: 64 bots in ONE pose graph; g32: 64 bots in 32 graphs
-if wl == "c1":
+if wl == "adv":
+    d = torch.from_numpy(replay.adversarial_stream(B)).cuda()
+    m = pkg.QuasarMapper(4096, 0.05, -102.4, -102.4, max_agent=2, exact_trig=False)
+elif wl == "c1":
     d = torch.from_numpy(replay.cycle_stream(session, B)).cuda()
     m = pkg.QuasarMapper(4096, 0.05, -102.4, -102.4, max_agent=2, exact_trig=False)
 else:
