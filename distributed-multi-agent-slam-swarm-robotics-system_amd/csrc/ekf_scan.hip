@@ -445,10 +445,20 @@ __device__ inline void es_prior(const EsWs &ws, const QsBatch &b, const double *
     }
 }
 
-__global__ void __launch_bounds__(64)
+typedef unsigned long long __attribute__((may_alias)) es_word;      // a chunk's element / coefficients, moved a word per lane
+
+// One WAVE per bot.  The walk over the bot's chunks is a strict recurrence, a 4 x 4 solve per chunk; what it must not do is
+// fetch the chunk's element (56 doubles) a lane per bot -- 64 lanes x 56 uncoalesced loads kept the address unit busy for
+// ~4 k cycles per chunk, more than the arithmetic.  Here the wave reads the element a lane per double (one coalesced request,
+// asked for a chunk ahead), passes it through LDS, and every lane does the same arithmetic on it (same operations, same order
+// as the lane-per-bot form: same doubles); lane 0 writes.
+__global__ void __launch_bounds__(QS_WAVE)
 es_apply_kernel(EsWs ws, QsBatch b, const double *__restrict__ ekf, const double *__restrict__ prev, int max_agent)
 {
-    const int bot = blockIdx.x * blockDim.x + threadIdx.x + 1;
+    constexpr int NW = (int)(sizeof(EsAgg1) / 8);
+    static_assert(sizeof(EsAgg1) % 8 == 0 && sizeof(EsAgg1) / 8 <= QS_WAVE, "element = at most one word per lane");
+    __shared__ EsAgg1 el[2];
+    const int bot = blockIdx.x + 1, lane = threadIdx.x;
     if (bot > max_agent || ws.count[bot] == 0) return;
     double x[6], P[36], s[4], A[16];
     es_prior(ws, b, ekf, prev, bot, x, P);
@@ -458,20 +468,29 @@ es_apply_kernel(EsWs ws, QsBatch b, const double *__restrict__ ekf, const double
         #pragma unroll
         for (int j = 0; j < 4; j++) A[4 * i + j] = P[6 * (2 + i) + 2 + j];
     }
-    for (unsigned int c = ws.chunk_base[bot]; c < ws.chunk_base[bot + 1]; c++) {
-        EsStart st;
-        #pragma unroll
-        for (int i = 0; i < 4; i++) st.s[i] = s[i];
-        #pragma unroll
-        for (int i = 0; i < 16; i++) st.A[i] = A[i];
-        ws.start[c] = st;
-        const EsAgg1 e = ws.agg1[c];
+    const unsigned int c0 = ws.chunk_base[bot], c1 = ws.chunk_base[bot + 1];
+    es_word nxt = (c0 < c1 && lane < NW) ? ((const es_word *)(ws.agg1 + c0))[lane] : 0ull;
+    int par = 0;
+    for (unsigned int c = c0; c < c1; c++, par ^= 1) {
+        if (lane < NW) ((es_word *)&el[par])[lane] = nxt;
+        if (c + 1 < c1 && lane < NW) nxt = ((const es_word *)(ws.agg1 + c + 1))[lane];
+        if (lane == 0) {
+            EsStart st;
+            #pragma unroll
+            for (int i = 0; i < 4; i++) st.s[i] = s[i];
+            #pragma unroll
+            for (int i = 0; i < 16; i++) st.A[i] = A[i];
+            ws.start[c] = st;
+        }
+        const EsAgg1 e = el[par];
         es_apply(e, s, A);
     }
-    #pragma unroll
-    for (int i = 0; i < 4; i++) ws.fin[(size_t)bot * 20 + i] = s[i];
-    #pragma unroll
-    for (int i = 0; i < 16; i++) ws.fin[(size_t)bot * 20 + 4 + i] = A[i];
+    if (lane == 0) {
+        #pragma unroll
+        for (int i = 0; i < 4; i++) ws.fin[(size_t)bot * 20 + i] = s[i];
+        #pragma unroll
+        for (int i = 0; i < 16; i++) ws.fin[(size_t)bot * 20 + 4 + i] = A[i];
+    }
 }
 
 // ---- E3: per chunk, from its start state: the 4x4 filter, and the coefficients of (p, B, D) ------
@@ -691,12 +710,16 @@ es_agg2_kernel(EsWs ws)
 }
 
 // ---- E4: fold (p, B, D) and the wrap count over the chunks, write the bot's state back ------------
-__global__ void __launch_bounds__(64)
+// (one wave per bot, the chunk's coefficients read a lane per word and a chunk ahead: as es_apply_kernel)
+__global__ void __launch_bounds__(QS_WAVE)
 es_fold_kernel(EsWs ws, QsBatch b, const double *__restrict__ recv_time, double t_nominal0,
                                double *__restrict__ ekf, double *__restrict__ prev, int max_agent,
                                unsigned long long *__restrict__ counters)
 {
-    const int bot = blockIdx.x * blockDim.x + threadIdx.x + 1;
+    constexpr int NW = (int)(sizeof(EsAgg2) / 8);
+    static_assert(sizeof(EsAgg2) % 8 == 0 && sizeof(EsAgg2) / 8 <= QS_WAVE, "coefficients = at most one word per lane");
+    __shared__ EsAgg2 el[2];
+    const int bot = blockIdx.x + 1, lane = threadIdx.x;
     if (bot > max_agent || ws.count[bot] == 0) return;
     double x[6], P[36];
     es_prior(ws, b, ekf, prev, bot, x, P);
@@ -709,8 +732,13 @@ es_fold_kernel(EsWs ws, QsBatch b, const double *__restrict__ recv_time, double 
     }
     int nw = 0;
     double last = prev[4 * bot + 3] != 0.0 ? ekf[(size_t)bot * 44 + 42] : -__builtin_inf();
-    for (unsigned int c = ws.chunk_base[bot]; c < ws.chunk_base[bot + 1]; c++) {
-        const EsAgg2 a = ws.agg2[c];
+    const unsigned int c0 = ws.chunk_base[bot], c1 = ws.chunk_base[bot + 1];
+    es_word nxt = (c0 < c1 && lane < NW) ? ((const es_word *)(ws.agg2 + c0))[lane] : 0ull;
+    int par = 0;
+    for (unsigned int c = c0; c < c1; c++, par ^= 1) {
+        if (lane < NW) ((es_word *)&el[par])[lane] = nxt;
+        if (c + 1 < c1 && lane < NW) nxt = ((const es_word *)(ws.agg2 + c + 1))[lane];
+        const EsAgg2 a = el[par];
         double BU[4], BW[8];
         #pragma unroll
         for (int rr = 0; rr < 2; rr++) {
@@ -756,10 +784,11 @@ es_fold_kernel(EsWs ws, QsBatch b, const double *__restrict__ recv_time, double 
         for (int i = 0; i < 8; i++) B[i] = Bn[i];
         // wrap count: the chunk evaluated the rule for wrap_c - 1, wrap_c, wrap_c + 1
         int k = nw - a.wrap_c + 1;
-        if (k < 0 || k > 2) { atomicAdd(&counters[QS_CNT_EKF_WRAP_CLAMP], 1ull); k = k < 0 ? 0 : 2; }
-        nw = a.wrap_out[k];
+        if (k < 0 || k > 2) { if (lane == 0) atomicAdd(&counters[QS_CNT_EKF_WRAP_CLAMP], 1ull); k = k < 0 ? 0 : 2; }
+        nw = k == 0 ? a.wrap_out[0] : k == 1 ? a.wrap_out[1] : a.wrap_out[2];      // (an index would send the whole struct to scratch)
         last = a.last_out;
     }
+    if (lane != 0) return;
     const double *fin = ws.fin + (size_t)bot * 20;
     double *f = ekf + (size_t)bot * 44;
     f[0] = p[0]; f[1] = p[1]; f[2] = fin[0] - ES_TWO_PI * (double)nw; f[3] = fin[1]; f[4] = fin[2]; f[5] = fin[3];
@@ -845,9 +874,9 @@ hipError_t qs_launch_ekf_scan(qs_ctx *c, size_t n, const double *d_time, hipStre
                        c->d_ekf_prev, c->cfg.ekf_metres_per_tick);
     hipLaunchKernelGGL(es_last_kernel, dim3((ma + 63) / 64), dim3(64), 0, st, ws, c->d_ekf, c->d_ekf_prev, ma);
     hipLaunchKernelGGL(es_agg1_kernel, dim3((chunks + QS_WAVE - 1) / QS_WAVE), dim3(QS_WAVE), 0, st, ws);
-    hipLaunchKernelGGL(es_apply_kernel, dim3((ma + 63) / 64), dim3(64), 0, st, ws, c->b, c->d_ekf, c->d_ekf_prev, ma);
+    hipLaunchKernelGGL(es_apply_kernel, dim3(ma), dim3(QS_WAVE), 0, st, ws, c->b, c->d_ekf, c->d_ekf_prev, ma);
     hipLaunchKernelGGL(es_agg2_kernel, dim3((chunks + QS_WAVE - 1) / QS_WAVE), dim3(QS_WAVE), 0, st, ws);
-    hipLaunchKernelGGL(es_fold_kernel, dim3((ma + 63) / 64), dim3(64), 0, st, ws, c->b, d_time, t0, c->d_ekf, c->d_ekf_prev, ma,
+    hipLaunchKernelGGL(es_fold_kernel, dim3(ma), dim3(QS_WAVE), 0, st, ws, c->b, d_time, t0, c->d_ekf, c->d_ekf_prev, ma,
                        c->d_counters);
     return hipGetLastError();
 }

@@ -9,6 +9,8 @@
 #include "qs_internal.h"
 
 static thread_local std::string g_create_err;
+static hipStream_t g_masked[64] = {};       // per device: the CU-masked stream its contexts' filters run on (ingest_device)
+static int g_masked_users[64] = {};
 static void chain_stats_poll(qs_ctx *c, bool synced);
 static int flush_edge_rays(qs_ctx *c);      // exact-trig mode: rays waiting for libm end points (defined with the ingest path)
 #define FLUSHCHK(c) do { int rcf__ = flush_edge_rays(c); if (rcf__ != QS_OK) return rcf__; } while (0)
@@ -288,7 +290,14 @@ extern "C" int qs_destroy(qs_ctx *c)
     hipFree(c->d_dirty); hipFree(c->d_counts_sent); hipFree(c->d_sf_bitmaps); hipFree(c->d_sf_lists); hipFree(c->d_sf_counts); hipFree(c->d_sf_payload);
     for (auto &p : c->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (auto e : c->ev_pool) hipEventDestroy(e);
-    if (c->ekf_stream) { hipStreamSynchronize(c->ekf_stream); if (!c->ekf_stream_shared) hipStreamDestroy(c->ekf_stream); }
+    if (c->ekf_stream) {
+        hipStreamSynchronize(c->ekf_stream);
+        if (!c->ekf_stream_shared) hipStreamDestroy(c->ekf_stream);
+        else if (c->device < 64 && --g_masked_users[c->device] == 0) {      // the last context of the device takes the shared stream with it
+            hipStreamDestroy(g_masked[c->device]);                           // (a profiler's exit handler trips over a CU-masked queue left behind)
+            g_masked[c->device] = nullptr;
+        }
+    }
     if (c->ev_decoded) hipEventDestroy(c->ev_decoded);
     if (c->ev_ekf_done) hipEventDestroy(c->ev_ekf_done);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
@@ -630,11 +639,10 @@ static int ingest_device(qs_ctx *c, const uint8_t *d_pkts, size_t n, size_t stri
                     words[0] = 0u;
                 }
             }
-            // ONE masked stream per device, shared by its contexts and never destroyed: a second CU-masked queue on the same GPU
+            // ONE masked stream per device, shared by its contexts (the last one destroys it): a second CU-masked queue on the same GPU
             // slows every kernel of the process by 30-50 % (measured: two contexts, each with its own masked stream, 1.81 ->
             // 2.79 ms per 64-bot step; tools/secondary_probe.py).  Contexts of one process then run their filters one after
             // the other, which is how they are driven anyway (a caller serialises the calls on a context).
-            static hipStream_t g_masked[64] = {};
             if (!words.empty() && c->device < 64) {
                 if (!g_masked[c->device] && hipExtStreamCreateWithCUMask(&g_masked[c->device], (uint32_t)words.size(), words.data()) != hipSuccess) {
                     (void)hipGetLastError();
@@ -642,6 +650,7 @@ static int ingest_device(qs_ctx *c, const uint8_t *d_pkts, size_t n, size_t stri
                 }
                 c->ekf_stream = g_masked[c->device];
                 c->ekf_stream_shared = c->ekf_stream != nullptr;
+                if (c->ekf_stream_shared) g_masked_users[c->device]++;
             }
             if (!c->ekf_stream)
                 HIPCHK(c, hipStreamCreateWithFlags(&c->ekf_stream, hipStreamNonBlocking));
