@@ -598,7 +598,9 @@ def run_rank(args):
         decisions = max(cnt["closures"], 1) / max(m.n_graphs * agents_per_graph, 1)
         cyc_unit = (cnt["slam_cycles"] / max(m.n_graphs, 1)) / decisions if free_running else cnt["slam_cycles"] / win
         roofline = {
-            "bound": "latency", "kernel": "qs_slam_chain_kernel (K4 loop-closure recurrence)",
+            "bound": "latency",
+            "kernel": ("qs_slam_chain_free_kernel" if free_running and agents_per_graph <= 13 else "qs_slam_chain_dyn_kernel" if free_running
+                       else "qs_slam_chain_kernel") + " (K4 loop-closure recurrence)",
             "achieved": alg_bytes / (dom_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": alg_bytes / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "traffic": None, "avg_launch_ms": dom_ms, "share_of_step": dom_ms / (elapsed / args.steps * 1e3),
