@@ -1128,7 +1128,7 @@ qs_slam_chain_free_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuc
         const QsU32G g_next = (QsU32G)Gp->nd_next;
         unsigned long long st_misc = 0, st_wait = 0;
 #ifdef QS_FREE_PROF
-        unsigned long long pf_wait = 0, pf_query = 0, pf_total0 = __builtin_amdgcn_s_memtime();
+        unsigned long long pf_wait = 0, pf_query = 0, pf_post = 0, pf_total0 = __builtin_amdgcn_s_memtime();
 #endif
         auto publish_prog = [&](long long nxt) {
             // what is handed over is the decision ring (LDS), written by this wave just before: the LDS unit takes a wave's
@@ -1161,6 +1161,9 @@ qs_slam_chain_free_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuc
             };
             unsigned long long elig = eligible();
             while (elig) {
+#if defined(QS_FREE_PROF) && QS_FREE_PROF == 3
+                const unsigned long long ts_ = __builtin_amdgcn_s_memtime();
+#endif
                 // (read early and relaxed: its latency hides behind the set-up below -- an older value is only more cautious --, and
                 // the acquire that orders the node loads after it comes with the query)
                 const long long fr0 = __hip_atomic_load(&s_frontier, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1177,6 +1180,9 @@ qs_slam_chain_free_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuc
                 long long gbest; double wx, wy;
 #ifdef QS_FREE_PROF
                 const unsigned long long tq_ = __builtin_amdgcn_s_memtime();
+#if QS_FREE_PROF == 3
+                pf_wait += tq_ - ts_;                                               // (profile build 3: decision set-up)
+#endif
 #endif
                 for (long long fr = fr0;; fr = lds_ld64(&s_frontier)) {
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");            // the index as of that frontier, not older
@@ -1224,6 +1230,9 @@ qs_slam_chain_free_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuc
                 // next chunk's first event)
                 elig = eligible();
                 publish_prog(elig ? rl64(idx, __ffsll((long long)elig) - 1) : next_first);
+#if defined(QS_FREE_PROF) && QS_FREE_PROF == 3
+                pf_post += __builtin_amdgcn_s_memtime() - tq_;                      // (query + everything after it)
+#endif
             }
             publish_prog(next_first);
         }
@@ -1236,6 +1245,7 @@ qs_slam_chain_free_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuc
             if (st_wait) { atomicAdd(&counters[QS_CNT_SLAM_ROUNDS], st_wait); if (pile_flag) atomicAdd(pile_flag + QS_FLAG_CHAIN_MISS - QS_FLAG_PILE, (unsigned int)st_wait); }
 #ifdef QS_FREE_PROF
             if (a == 0) { atomicAdd(&counters[QS_CNT_SLAM_CYC_A], pf_wait); atomicAdd(&counters[QS_CNT_SLAM_CYC_B], pf_query);
+                          if (QS_FREE_PROF == 3) atomicAdd(&counters[QS_CNT_SLAM_CYC_C], pf_post);
                           atomicAdd(&counters[QS_CNT_SLAM_NODE_ITERS], __builtin_amdgcn_s_memtime() - pf_total0); }
 #endif
         }
@@ -1365,7 +1375,7 @@ qs_slam_chain_free_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuc
             atomicAdd(&counters[QS_CNT_LANDMARKS], (unsigned long long)(n_lms - G.n_lms));
             atomicAdd(&counters[QS_CNT_SLAM_WINDOWS], st_batches);
 #ifdef QS_FREE_PROF
-            atomicAdd(&counters[QS_CNT_SLAM_CYC_C], pf_idle);
+            if (QS_FREE_PROF != 3) atomicAdd(&counters[QS_CNT_SLAM_CYC_C], pf_idle);
             atomicAdd(&counters[QS_CNT_EKF_WRAP_CLAMP], pf_agents); if (QS_FREE_PROF != 2) atomicAdd(&counters[QS_CNT_SLAM_MISC_ITERS], pf_insert);
 #endif
             atomicAdd(&counters[QS_CNT_SLAM_CYCLES], __builtin_amdgcn_s_memtime() - t0_cyc);

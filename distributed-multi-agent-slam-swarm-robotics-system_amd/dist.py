@@ -316,9 +316,9 @@ class ShardedMapper:
 
     def ingest(self, d_pkts, d_time=None, seq_base=0):
         """d_pkts: uint8 [B, stride] device tensor (this rank's batch); d_time: float64 [B] or None;
-        seq_base: global arrival index of record 0 of rank 0's batch.  The work is enqueued on the context's stream; with
-        exact_trig (the default) the call ends with one stream synchronisation (the edge-ray count is read back), with
-        exact_trig = False it returns without waiting for the GPU."""
+        seq_base: global arrival index of record 0 of rank 0's batch.  The work is enqueued on the context's stream and the
+        call returns without waiting for the GPU (exact-trig edge rays wait on the device until the map is next observed:
+        a fuse, a grid read, sync)."""
         import torch
         import torch.distributed as dist
         B, stride = d_pkts.shape
