@@ -2,6 +2,7 @@
 // pipeline  decode (K0) -> SLAM drift (K4) -> raycast (K1) [-> EKF (K5)]  on one HIP stream.
 #include <math.h>
 #include <algorithm>
+#include <mutex>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -11,6 +12,7 @@
 static thread_local std::string g_create_err;
 static hipStream_t g_masked[64] = {};       // per device: the CU-masked stream its contexts' filters run on (ingest_device)
 static int g_masked_users[64] = {};
+static std::mutex g_masked_mutex;           // (contexts are independent: two threads may create / destroy theirs at the same time)
 static void chain_stats_poll(qs_ctx *c, bool synced);
 static int flush_edge_rays(qs_ctx *c);      // exact-trig mode: rays waiting for libm end points (defined with the ingest path)
 #define FLUSHCHK(c) do { int rcf__ = flush_edge_rays(c); if (rcf__ != QS_OK) return rcf__; } while (0)
@@ -293,9 +295,12 @@ extern "C" int qs_destroy(qs_ctx *c)
     if (c->ekf_stream) {
         hipStreamSynchronize(c->ekf_stream);
         if (!c->ekf_stream_shared) hipStreamDestroy(c->ekf_stream);
-        else if (c->device < 64 && --g_masked_users[c->device] == 0) {      // the last context of the device takes the shared stream with it
-            hipStreamDestroy(g_masked[c->device]);                           // (a profiler's exit handler trips over a CU-masked queue left behind)
-            g_masked[c->device] = nullptr;
+        else if (c->device < 64) {
+            std::lock_guard<std::mutex> lk(g_masked_mutex);
+            if (--g_masked_users[c->device] == 0) {                          // the last context of the device takes the shared stream with it
+                hipStreamDestroy(g_masked[c->device]);                       // (a profiler's exit handler trips over a CU-masked queue left behind)
+                g_masked[c->device] = nullptr;
+            }
         }
     }
     if (c->ev_decoded) hipEventDestroy(c->ev_decoded);
@@ -644,6 +649,7 @@ static int ingest_device(qs_ctx *c, const uint8_t *d_pkts, size_t n, size_t stri
             // 2.79 ms per 64-bot step; tools/secondary_probe.py).  Contexts of one process then run their filters one after
             // the other, which is how they are driven anyway (a caller serialises the calls on a context).
             if (!words.empty() && c->device < 64) {
+                std::lock_guard<std::mutex> lk(g_masked_mutex);
                 if (!g_masked[c->device] && hipExtStreamCreateWithCUMask(&g_masked[c->device], (uint32_t)words.size(), words.data()) != hipSuccess) {
                     (void)hipGetLastError();
                     g_masked[c->device] = nullptr;

@@ -985,6 +985,9 @@ __device__ inline long long free_query(const QsGraphDev *Gp, QsNodeG g_nodes, Qs
     const int dense_after = (int)((nl >> 9) > 8 ? ((nl >> 9) < 100000 ? (nl >> 9) : 100000) : 8);
     int rounds = 0;
     bool dense = false;
+#if defined(QS_FREE_PROF) && QS_FREE_PROF == 5
+    const unsigned long long tl_ = __builtin_amdgcn_s_memtime();
+#endif
     while (__ballot(node != 0)) {
         if (DENSE && rounds++ == dense_after) { dense = true; break; }
 #if defined(QS_FREE_PROF) && QS_FREE_PROF == 2
@@ -1014,6 +1017,9 @@ __device__ inline long long free_query(const QsGraphDev *Gp, QsNodeG g_nodes, Qs
         const bool b_full = ((limm >> last_lane) & 1ull) != 0;
         if (node) node = (b_hit || !b_full || nxt == 0 || lastid >= gbest) ? 0u : nxt;
     }
+#if defined(QS_FREE_PROF) && QS_FREE_PROF == 5
+    st_misc += __builtin_amdgcn_s_memtime() - tl_;                       // (profile build 5: the node rounds)
+#endif
     wx = 0; wy = 0;
     if (DENSE && dense) {
         // self.landmarks in insertion order (:294), a wave wide; the scan ends at the first entry that is too new
@@ -1149,6 +1155,9 @@ qs_slam_chain_free_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuc
         int ag_n = -1, type_n = 0; long long idx_n = LL_MAX, nf_n = LL_MAX; double px_n = 0, py_n = 0;
         if (e0 < e1) load_chunk(e0, ag_n, idx_n, type_n, px_n, py_n, nf_n);
         for (unsigned int q0 = e0; q0 < e1; q0 += QS_WAVE) {
+#if defined(QS_FREE_PROF) && QS_FREE_PROF == 4
+            const unsigned long long tc_ = __builtin_amdgcn_s_memtime();
+#endif
             const int ag = ag_n, type = type_n;
             const long long idx = idx_n, next_first = nf_n;
             const double px = px_n, py = py_n;
@@ -1160,6 +1169,9 @@ qs_slam_chain_free_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuc
                 return own & ~done & __ballot(idx - c_last >= min_between);
             };
             unsigned long long elig = eligible();
+#if defined(QS_FREE_PROF) && QS_FREE_PROF == 4
+            pf_wait += __builtin_amdgcn_s_memtime() - tc_;                         // (profile build 4: top of a chunk)
+#endif
             while (elig) {
 #if defined(QS_FREE_PROF) && QS_FREE_PROF == 3
                 const unsigned long long ts_ = __builtin_amdgcn_s_memtime();
@@ -1186,6 +1198,10 @@ qs_slam_chain_free_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuc
 #endif
                 for (long long fr = fr0;; fr = lds_ld64(&s_frontier)) {
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");            // the index as of that frontier, not older
+#if defined(QS_FREE_PROF) && QS_FREE_PROF == 4
+                    const unsigned long long tf_ = __builtin_amdgcn_s_memtime();
+                    pf_post += tf_ - tq_;                                           // (the fence, the first time round)
+#endif
                     const long long nm = s_nmisc, nl = DENSE ? s_nlms : 0;
                     gbest = free_query<DENSE>(Gp, g_nodes, g_next, bg, qx, qy, qtype, fr < limit ? fr : limit, r2thr, nm, nl, lane, wx, wy, st_misc);
                     if (gbest != LL_MAX || fr >= limit) break;                      // a match below the frontier is final; so is "none" once all are in
@@ -1245,7 +1261,7 @@ qs_slam_chain_free_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuc
             if (st_wait) { atomicAdd(&counters[QS_CNT_SLAM_ROUNDS], st_wait); if (pile_flag) atomicAdd(pile_flag + QS_FLAG_CHAIN_MISS - QS_FLAG_PILE, (unsigned int)st_wait); }
 #ifdef QS_FREE_PROF
             if (a == 0) { atomicAdd(&counters[QS_CNT_SLAM_CYC_A], pf_wait); atomicAdd(&counters[QS_CNT_SLAM_CYC_B], pf_query);
-                          if (QS_FREE_PROF == 3) atomicAdd(&counters[QS_CNT_SLAM_CYC_C], pf_post);
+                          if (QS_FREE_PROF >= 3) atomicAdd(&counters[QS_CNT_SLAM_CYC_C], pf_post);
                           atomicAdd(&counters[QS_CNT_SLAM_NODE_ITERS], __builtin_amdgcn_s_memtime() - pf_total0); }
 #endif
         }
@@ -1375,8 +1391,8 @@ qs_slam_chain_free_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuc
             atomicAdd(&counters[QS_CNT_LANDMARKS], (unsigned long long)(n_lms - G.n_lms));
             atomicAdd(&counters[QS_CNT_SLAM_WINDOWS], st_batches);
 #ifdef QS_FREE_PROF
-            if (QS_FREE_PROF != 3) atomicAdd(&counters[QS_CNT_SLAM_CYC_C], pf_idle);
-            atomicAdd(&counters[QS_CNT_EKF_WRAP_CLAMP], pf_agents); if (QS_FREE_PROF != 2) atomicAdd(&counters[QS_CNT_SLAM_MISC_ITERS], pf_insert);
+            if (QS_FREE_PROF < 3) atomicAdd(&counters[QS_CNT_SLAM_CYC_C], pf_idle);
+            atomicAdd(&counters[QS_CNT_EKF_WRAP_CLAMP], pf_agents); if (QS_FREE_PROF == 1) atomicAdd(&counters[QS_CNT_SLAM_MISC_ITERS], pf_insert);
 #endif
             atomicAdd(&counters[QS_CNT_SLAM_CYCLES], __builtin_amdgcn_s_memtime() - t0_cyc);
             atomicAdd(&counters[QS_CNT_SLAM_REALTIME], __builtin_amdgcn_s_memrealtime() - t0_real);
@@ -1697,7 +1713,7 @@ qs_slam_chain_dyn_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuck
             atomicAdd(&counters[QS_CNT_SLAM_WINDOWS], st_batches);
 #ifdef QS_FREE_PROF
             atomicAdd(&counters[QS_CNT_SLAM_CYC_C], pf_idle);
-            atomicAdd(&counters[QS_CNT_EKF_WRAP_CLAMP], pf_agents); if (QS_FREE_PROF != 2) atomicAdd(&counters[QS_CNT_SLAM_MISC_ITERS], pf_insert);
+            atomicAdd(&counters[QS_CNT_EKF_WRAP_CLAMP], pf_agents); if (QS_FREE_PROF == 1) atomicAdd(&counters[QS_CNT_SLAM_MISC_ITERS], pf_insert);
 #endif
             atomicAdd(&counters[QS_CNT_SLAM_CYCLES], __builtin_amdgcn_s_memtime() - t0_cyc);
             atomicAdd(&counters[QS_CNT_SLAM_REALTIME], __builtin_amdgcn_s_memrealtime() - t0_real);
