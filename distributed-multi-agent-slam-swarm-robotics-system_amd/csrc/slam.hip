@@ -1803,7 +1803,10 @@ hipError_t qs_launch_slam_reset_index(qs_ctx *c)
     if (!c->d_graphs || c->n_graphs <= 0) return hipSuccess;
     const unsigned int first_pool = (unsigned int)(1 + c->dir_entries);
     const int nb = c->cfg.max_agent + 1, m = nb > c->n_graphs ? nb : c->n_graphs;
-    hipLaunchKernelGGL(qs_slam_reset_index_kernel, dim3(64, c->n_graphs), dim3(256), 0, c->stream, c->d_graphs, c->bg, first_pool);
+    // (one graph can hold the whole session's landmarks -- 2 x 10^5 entries of 32 words after one configs[1] step --: enough
+    // workgroups to fill the chip whatever the number of graphs; 64 per graph took 0.28 ms there, 2048 take 0.03)
+    const int per_graph = c->n_graphs >= 32 ? 64 : 2048 / c->n_graphs;
+    hipLaunchKernelGGL(qs_slam_reset_index_kernel, dim3(per_graph, c->n_graphs), dim3(256), 0, c->stream, c->d_graphs, c->bg, first_pool);
     hipLaunchKernelGGL(qs_slam_reset_counters_kernel, dim3((m + 255) / 256), dim3(256), 0, c->stream, c->d_graphs, c->n_graphs,
                        first_pool, c->d_last_closure, nb, -(long long)c->cfg.min_poses_between);
     return hipGetLastError();
