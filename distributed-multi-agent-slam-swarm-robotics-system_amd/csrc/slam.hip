@@ -968,18 +968,35 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
 
 // one query: the reference's first match among the landmarks of type qtype with node index <= eff, within the radius of
 // (qx, qy); lane = (bucket of the 3 x 3 neighbourhood, entry of that bucket's current node).  LL_MAX: none.
+// (the pieces of a query's first round, so that an owner can have the NEXT decision's rows on their way while it works on this one)
+struct FqRows { long long id, lastid; double nx, ny; unsigned int nxt; };
+// the lane's node: the first node of its bucket of the 3 x 3 around (qx, qy); 0: none.  (qcx, qcy): the centre cell
+__device__ inline unsigned int fq_node0(const QsBucketGeom &bg, double qx, double qy, int qtype, int lane, int &qcx, int &qcy)
+{
+    const int nbk = lane / QS_NODE_CAP;
+    const int nb_dx = (nbk % 3) - 1, nb_dy = (nbk / 3) - 1;
+    const bool indexed = bucket_cell(qx, qy, qtype, bg, qcx, qcy);
+    return (indexed && lane < 9 * QS_NODE_CAP) ? 1u + (unsigned int)bucket_key(qtype, qcx + nb_dx, qcy + nb_dy, bg) : 0u;
+}
+__device__ inline void fq_load(QsNodeG g_nodes, QsU32G g_next, unsigned int node, int lane, FqRows &r)
+{
+    const int se = lane % QS_NODE_CAP;
+    r.id = LL_MAX; r.lastid = LL_MAX; r.nx = 0; r.ny = 0; r.nxt = 0;
+    if (node) {
+        const QsNodeG nd = g_nodes + node;
+        r.id = nd->idx[se]; r.lastid = nd->idx[QS_NODE_CAP - 1]; r.nx = nd->x[se]; r.ny = nd->y[se]; r.nxt = g_next[node];
+    }
+}
+// pre: the rows of the first nodes (node0), loaded by the caller -- complete for every entry up to the frontier it read before
+// it asked for them, which is what eff must not exceed
 template <bool DENSE>
 __device__ inline long long free_query(const QsGraphDev *Gp, QsNodeG g_nodes, QsU32G g_next, const QsBucketGeom &bg, double qx, double qy,
                                        int qtype, long long eff, double r2thr, long long nm, long long nl, int lane, double &wx, double &wy,
-                                       unsigned long long &st_misc)
+                                       unsigned long long &st_misc, unsigned int node0, bool use_pre, const FqRows &pre)
 {
-    const int nbk = lane / QS_NODE_CAP, se = lane % QS_NODE_CAP;
+    const int nbk = lane / QS_NODE_CAP;
     const int last_lane = min(nbk * QS_NODE_CAP + QS_NODE_CAP - 1, 63);
-    const int nb_dx = (nbk % 3) - 1, nb_dy = (nbk / 3) - 1;
-    int qcx, qcy;
-    const bool indexed = bucket_cell(qx, qy, qtype, bg, qcx, qcy);
-    unsigned int node = 0;
-    if (indexed && lane < 9 * QS_NODE_CAP) node = 1u + (unsigned int)bucket_key(qtype, qcx + nb_dx, qcy + nb_dy, bg);
+    unsigned int node = node0;
     long long best = LL_MAX, gbest = LL_MAX;
     double bx = 0, by = 0;
     const int dense_after = (int)((nl >> 9) > 8 ? ((nl >> 9) < 100000 ? (nl >> 9) : 100000) : 8);
@@ -993,13 +1010,12 @@ __device__ inline long long free_query(const QsGraphDev *Gp, QsNodeG g_nodes, Qs
 #if defined(QS_FREE_PROF) && QS_FREE_PROF == 2
         st_misc++;                                                       // (profile build: node rounds)
 #endif
-        long long id = LL_MAX, lastid = LL_MAX;
-        double nx = 0, ny = 0;
-        unsigned int nxt = 0;
-        if (node) {
-            const QsNodeG nd = g_nodes + node;
-            id = nd->idx[se]; lastid = nd->idx[QS_NODE_CAP - 1]; nx = nd->x[se]; ny = nd->y[se]; nxt = g_next[node];
-        }
+        FqRows r;
+        if (use_pre) { r = pre; use_pre = false; }                        // (by value and a flag: a pointer would put the rows in scratch)
+        else fq_load(g_nodes, g_next, node, lane, r);
+        const long long id = r.id, lastid = r.lastid;
+        const double nx = r.nx, ny = r.ny;
+        const unsigned int nxt = r.nxt;
         const bool inlim = node != 0 && id <= eff;                       // empty slots read as a huge index
         bool newhit = false;
         if (inlim && best == LL_MAX) {
@@ -1082,8 +1098,10 @@ __device__ inline void lds_st64(long long *p, long long v) { __hip_atomic_store(
 __device__ inline unsigned int lds_ld32(const unsigned int *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ inline void lds_st32(unsigned int *p, unsigned int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
-template <bool DENSE>
-__global__ void __launch_bounds__(CH_THREADS)
+// WAVES: 16, or 8 for graphs of up to 5 agents -- half the waves per SIMD is twice the registers per wave (256), and the owner keeps
+// two chunks of events and two decisions' bucket rows in registers.
+template <bool DENSE, int WAVES>
+__global__ void __launch_bounds__(WAVES * QS_WAVE)
 qs_slam_chain_free_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGeom bg, int bots_per_graph,
                           int max_agent, int min_between, double r2thr, double corr,
                           double *__restrict__ drift, long long *__restrict__ last_closure,
@@ -1093,8 +1111,9 @@ qs_slam_chain_free_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuc
     QsGraphDev *const Gp = graphs + g;
     const int bot0 = g * bots_per_graph + 1;
     const int nb = min(bots_per_graph, max_agent - bot0 + 1);
-    const int n_ow = min(CH_AGW, nb);               // owner waves in use
-    constexpr int NA = CH_AGW;                      // (graphs with more agents: qs_slam_chain_dyn_kernel)
+    constexpr int AGW = WAVES - 3, INS = WAVES - 1, THREADS = WAVES * QS_WAVE;   // owner waves 1 .. AGW; the committer
+    const int n_ow = min(AGW, nb);                  // owner waves in use
+    constexpr int NA = AGW;                         // (graphs with more agents: qs_slam_chain_dyn_kernel)
     constexpr int RD = FR_RING;                     // decisions an agent can be ahead of the committer
 
     // An owner hands the committer its DECISIONS only -- (closing node, matched landmark, correction), in the agent's order, in a
@@ -1104,7 +1123,7 @@ qs_slam_chain_free_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuc
     __shared__ long long q_idx[NA][RD], q_midx[NA][RD];                         // closing node; matched landmark's node
     __shared__ double q_cdx[NA][RD], q_cdy[NA][RD];                             // the closure's correction (:314-315)
     __shared__ unsigned int s_push[NA], s_cons[NA];                             // decisions pushed by the owner / taken by the committer
-    __shared__ long long s_prog[CH_AGW];          // every event of the owner's agents with a node index below this is decided (LL_MAX: all)
+    __shared__ long long s_prog[AGW];          // every event of the owner's agents with a node index below this is decided (LL_MAX: all)
     __shared__ long long s_frontier;              // every landmark with node index <= this is in the index, complete and visible
     __shared__ long long s_nmisc, s_nlms;         // side-list / log entries that go with that frontier
     // committer's own: every agent's drift as of the events it has passed, and where the agent's next closure record goes
@@ -1112,11 +1131,11 @@ qs_slam_chain_free_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuc
     __shared__ unsigned int c_apos[NA];
 
     const unsigned int e0 = sb.ev_base[g], e1 = sb.ev_base[g + 1];
-    for (int t = tid; t < NA; t += CH_THREADS) {
+    for (int t = tid; t < NA; t += THREADS) {
         s_push[t] = 0; s_cons[t] = 0;
         if (t < nb) { c_ddx[t] = drift[2 * (bot0 + t)]; c_ddy[t] = drift[2 * (bot0 + t) + 1]; c_apos[t] = sb.agent_ev[bot0 + t]; }
     }
-    if (tid < CH_AGW) s_prog[tid] = tid < n_ow ? (e0 < e1 ? sb.ev_node[e0] : LL_MAX) : LL_MAX;
+    if (tid < AGW) s_prog[tid] = tid < n_ow ? (e0 < e1 ? sb.ev_node[e0] : LL_MAX) : LL_MAX;
     if (tid == 0) { s_frontier = e0 < e1 ? sb.ev_node[e0] - 1 : LL_MAX; s_nmisc = Gp->n_misc; s_nlms = Gp->n_lms; }
     __syncthreads();
 
@@ -1172,50 +1191,71 @@ qs_slam_chain_free_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuc
 #if defined(QS_FREE_PROF) && QS_FREE_PROF == 4
             pf_wait += __builtin_amdgcn_s_memtime() - tc_;                         // (profile build 4: top of a chunk)
 #endif
-            while (elig) {
-#if defined(QS_FREE_PROF) && QS_FREE_PROF == 3
-                const unsigned long long ts_ = __builtin_amdgcn_s_memtime();
-#endif
-                // (read early and relaxed: its latency hides behind the set-up below -- an older value is only more cautious --, and
-                // the acquire that orders the node loads after it comes with the query)
-                const long long fr0 = __hip_atomic_load(&s_frontier, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                const int f = __ffsll((long long)elig) - 1;
-                const int qa = a;
-                const long long qidx = rl64(idx, f);
-                const double odx = c_dx, ody = c_dy;
+            // A decision: (event f of the chunk, its pose with the agent's drift as it is NOW, the first nodes of its nine buckets,
+            // their rows on the way).  The rows of the NEXT decision are asked for as soon as this one's closure is known -- before
+            // the hand-over to the committer, whose LDS traffic then runs in the shadow of the loads.
+            int f = 0, qtype = 0;
+            long long qidx = 0, fr_rows = 0;
+            double qx = 0, qy = 0;
+            unsigned int node0 = 0;
+            FqRows rows = {LL_MAX, LL_MAX, 0, 0, 0u};
+            auto start_decision = [&](unsigned long long e_) {
+                // (the frontier first: the rows are asked for after it is read -- an older value is only more cautious)
+                fr_rows = __hip_atomic_load(&s_frontier, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                f = __ffsll((long long)e_) - 1;
+                qidx = rl64(idx, f);
                 const double spx = rlf64(px, f), spy = rlf64(py, f);
-                const double qx = raw_pose ? spx : spx + odx, qy = raw_pose ? spy : spy + ody;   // rx += cdx  :856-857
-                const int qtype = __builtin_amdgcn_readlane(type, f);
+                qx = raw_pose ? spx : spx + c_dx; qy = raw_pose ? spy : spy + c_dy;               // rx += cdx  :856-857
+                qtype = __builtin_amdgcn_readlane(type, f);
+                int qcx, qcy;
+                node0 = fq_node0(bg, qx, qy, qtype, lane, qcx, qcy);
+                __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                fq_load(g_nodes, g_next, node0, lane, rows);
+            };
+            if (elig) start_decision(elig);
+            while (elig) {
+                const int qa = a;
+                const long long qidx_c = qidx;                                      // (this decision's: start_decision below moves on)
+                const double qx_c = qx, qy_c = qy;
                 // :300 -- and a node never sees its own landmark (appended after the check, :288): with MIN_POSES_BETWEEN < 1
                 // the newest landmark a query can see is still the one before it
-                const long long limit = qidx - (min_between > 1 ? min_between : 1);
+                const long long limit = qidx_c - (min_between > 1 ? min_between : 1);
                 long long gbest; double wx, wy;
 #ifdef QS_FREE_PROF
                 const unsigned long long tq_ = __builtin_amdgcn_s_memtime();
-#if QS_FREE_PROF == 3
-                pf_wait += tq_ - ts_;                                               // (profile build 3: decision set-up)
 #endif
-#endif
-                for (long long fr = fr0;; fr = lds_ld64(&s_frontier)) {
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");            // the index as of that frontier, not older
-#if defined(QS_FREE_PROF) && QS_FREE_PROF == 4
-                    const unsigned long long tf_ = __builtin_amdgcn_s_memtime();
-                    pf_post += tf_ - tq_;                                           // (the fence, the first time round)
-#endif
-                    const long long nm = s_nmisc, nl = DENSE ? s_nlms : 0;
-                    gbest = free_query<DENSE>(Gp, g_nodes, g_next, bg, qx, qy, qtype, fr < limit ? fr : limit, r2thr, nm, nl, lane, wx, wy, st_misc);
-                    if (gbest != LL_MAX || fr >= limit) break;                      // a match below the frontier is final; so is "none" once all are in
-                    st_wait++;
-                    publish_prog(qidx);                                             // (the committer has to get past this owner's older events)
-                    FR_SPIN(lds_ld64(&s_frontier) < limit);
+                {
+                    bool pre = true;
+                    for (long long fr = fr_rows;;) {
+                        const long long nm = s_nmisc, nl = DENSE ? s_nlms : 0;
+                        gbest = free_query<DENSE>(Gp, g_nodes, g_next, bg, qx_c, qy_c, qtype, fr < limit ? fr : limit, r2thr, nm, nl, lane, wx, wy, st_misc,
+                                                  node0, pre, rows);
+                        if (gbest != LL_MAX || fr >= limit) break;                  // a match below the frontier is final; so is "none" once all are in
+                        pre = false;
+                        if (lds_ld64(&s_frontier) <= fr) {                          // nothing new since those rows: the committer has to come closer
+                            st_wait++;
+                            publish_prog(qidx_c);                                   // (it has to get past this owner's older events)
+                            FR_SPIN(lds_ld64(&s_frontier) < limit);
+                        }
+                        fr = lds_ld64(&s_frontier);
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");        // the index as of that frontier, not older
+                    }
                 }
 #ifdef QS_FREE_PROF
                 pf_query += __builtin_amdgcn_s_memtime() - tq_;
 #endif
                 done |= (2ull << f) - 1;                                            // (lanes up to f: decided)
+                double cdx = 0, cdy = 0;
                 if (gbest != LL_MAX) {
-                    const double ex = wx - qx, ey = wy - qy;                        // :311-312
-                    const double cdx = ex * corr, cdy = ey * corr;                  // :314-315
+                    const double ex = wx - qx_c, ey = wy - qy_c;                    // :311-312
+                    cdx = ex * corr; cdy = ey * corr;                               // :314-315
+                    c_dx += cdx; c_dy += cdy; c_last = qidx_c;                      // :911-914, :318
+                }
+                // the next decision, its rows on the way ...
+                elig = eligible();
+                if (elig) start_decision(elig);
+                // ... and this one handed over
+                if (gbest != LL_MAX) {
                     // the agent's decision ring: a slot must be free
                     unsigned int pq = pushed, cq = cons_c;
                     if (pq - cq >= (unsigned int)RD) {                              // looks full
@@ -1224,7 +1264,7 @@ qs_slam_chain_free_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuc
 #ifdef QS_FREE_PROF
                             const unsigned long long t_ = __builtin_amdgcn_s_memtime();
 #endif
-                            publish_prog(qidx);
+                            publish_prog(qidx_c);
                             FR_SPIN(pq - (cq = lds_ld32(&s_cons[qa])) >= (unsigned int)RD);
 #ifdef QS_FREE_PROF
                             pf_wait += __builtin_amdgcn_s_memtime() - t_;
@@ -1233,19 +1273,15 @@ qs_slam_chain_free_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuc
                     }
                     if (lane == 0) {
                         const unsigned int sl = pq % RD;
-                        q_idx[qa][sl] = qidx; q_midx[qa][sl] = gbest; q_cdx[qa][sl] = cdx; q_cdy[qa][sl] = cdy;
+                        q_idx[qa][sl] = qidx_c; q_midx[qa][sl] = gbest; q_cdx[qa][sl] = cdx; q_cdy[qa][sl] = cdy;
                     }
-                    {
-                        c_dx += cdx; c_dy += cdy; c_last = qidx;                    // :911-914, :318
-                        pushed = pq + 1; cons_c = cq;
-                    }
+                    pushed = pq + 1; cons_c = cq;
                     __asm__ volatile("" ::: "memory");
                     if (lane == 0) __hip_atomic_store(&s_push[qa], pq + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
                 // decided: everything of this owner below its next event that may close (or, failing one in this chunk, below the
                 // next chunk's first event)
-                elig = eligible();
-                publish_prog(elig ? rl64(idx, __ffsll((long long)elig) - 1) : next_first);
+                publish_prog(elig ? qidx : next_first);
 #if defined(QS_FREE_PROF) && QS_FREE_PROF == 3
                 pf_post += __builtin_amdgcn_s_memtime() - tq_;                      // (query + everything after it)
 #endif
@@ -1265,7 +1301,7 @@ qs_slam_chain_free_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuc
                           atomicAdd(&counters[QS_CNT_SLAM_NODE_ITERS], __builtin_amdgcn_s_memtime() - pf_total0); }
 #endif
         }
-    } else if (wave == CH_INS) {
+    } else if (wave == INS) {
         // =================================== the committer ===================================
         const QsGraphDev G = *Gp;
         long long n_lms = G.n_lms, n_misc = G.n_misc, n_cls = G.n_cls;
@@ -1551,7 +1587,9 @@ qs_slam_chain_dyn_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuck
                 for (long long fr = fr0;; fr = lds_ld64(&s_frontier)) {
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");            // the index as of that frontier, not older
                     const long long nm = s_nmisc, nl = DENSE ? s_nlms : 0;
-                    gbest = free_query<DENSE>(Gp, g_nodes, g_next, bg, qx, qy, qtype, fr < limit ? fr : limit, r2thr, nm, nl, lane, wx, wy, st_misc);
+                    int qcx_, qcy_;
+                    gbest = free_query<DENSE>(Gp, g_nodes, g_next, bg, qx, qy, qtype, fr < limit ? fr : limit, r2thr, nm, nl, lane, wx, wy, st_misc,
+                                              fq_node0(bg, qx, qy, qtype, lane, qcx_, qcy_), false, FqRows{LL_MAX, LL_MAX, 0, 0, 0u});
                     if (gbest != LL_MAX || fr >= limit) break;                      // a match below the frontier is final; so is "none" once all are in
                     st_wait++;
                     FR_SPIN(lds_ld64(&s_frontier) < limit);
@@ -1836,14 +1874,15 @@ hipError_t qs_launch_slam(qs_ctx *c, size_t n, bool raw_pose)
     // (chain_stats_poll in qs_api.hip reads the counts, without waiting for anything).  Same results either way.
     const bool free_mode = c->chain_form == QS_CHAIN_FREE || (c->chain_form == QS_CHAIN_AUTO && !(one && c->chain_windowed));
     c->chain_last_free = free_mode;
-#define FR_LAUNCH(DENSE_) hipLaunchKernelGGL((qs_slam_chain_free_kernel<DENSE_>), dim3(G), dim3(CH_THREADS), 0, c->stream, c->d_graphs, sb, c->bg, \
+#define FR_LAUNCH(DENSE_, WAVES_) hipLaunchKernelGGL((qs_slam_chain_free_kernel<DENSE_, WAVES_>), dim3(G), dim3(WAVES_ * QS_WAVE), 0, c->stream, c->d_graphs, sb, c->bg, \
                            c->bots_per_graph, c->cfg.max_agent, c->cfg.min_poses_between, c->r2_threshold,                                  \
                            c->cfg.closure_correction, c->d_drift, c->d_last_closure, c->d_counters, raw_pose ? 1 : 0, c->d_flags + QS_FLAG_PILE)
 #define DY_LAUNCH(DENSE_) hipLaunchKernelGGL((qs_slam_chain_dyn_kernel<DENSE_>), dim3(G), dim3(CH_THREADS), 0, c->stream, c->d_graphs, sb, c->bg, \
                            c->bots_per_graph, c->cfg.max_agent, c->cfg.min_poses_between, c->r2_threshold,                                  \
                            c->cfg.closure_correction, c->d_drift, c->d_last_closure, c->d_counters, raw_pose ? 1 : 0, c->d_flags + QS_FLAG_PILE)
     if (free_mode) {
-        if (one) { if (c->pile_mode) FR_LAUNCH(true); else FR_LAUNCH(false); }
+        if (one && c->bots_per_graph <= 5) { if (c->pile_mode) FR_LAUNCH(true, 8); else FR_LAUNCH(false, 8); }
+        else if (one) { if (c->pile_mode) FR_LAUNCH(true, 16); else FR_LAUNCH(false, 16); }
         else { if (c->pile_mode) DY_LAUNCH(true); else DY_LAUNCH(false); }
     }
 #undef DY_LAUNCH
