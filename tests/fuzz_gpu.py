@@ -67,8 +67,10 @@ for it in range(n_iter):
     o.set_closure_params(radius, mb, corr)
     o.feed_stream(stream)
     cuts = sorted(set([0, n] + [int(c) for c in rng.integers(0, n, int(rng.integers(0, 4)))]))
+    form = str(rng.choice(["auto", "free", "window"]))
     with pkg.QuasarMapper(512, 0.05, -12.8, -12.8, max_agent=nb, bots_per_graph=bpg, closure_radius=radius,
                           min_poses_between=mb, closure_correction=corr) as m:
+        m.set_chain_form(form)
         for a, b in zip(cuts[:-1], cuts[1:]):
             m.ingest_array(stream[a:b])
         ok = (m.grid_i8() == o.grid).all()
@@ -82,6 +84,6 @@ for it in range(n_iter):
             ok &= np.allclose(m.drift(b), o.drift(b), rtol=0, atol=1e-9)
     if not ok:
         bad2 += 1
-        print("MISMATCH(slam)", dict(it=it, nb=nb, bpg=bpg, radius=radius, mb=mb, corr=corr, n=n, cuts=cuts))
+        print("MISMATCH(slam)", dict(it=it, nb=nb, bpg=bpg, radius=radius, mb=mb, corr=corr, n=n, cuts=cuts, form=form))
 print("slam fuzz done:", n_iter, "cases,", bad2, "mismatches")
 sys.exit(1 if bad or bad2 else 0)
