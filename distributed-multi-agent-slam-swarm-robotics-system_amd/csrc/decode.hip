@@ -47,6 +47,17 @@ qs_decode_kernel(const unsigned char *__restrict__ pkts, size_t n, size_t stride
     const size_t ndw = (mis + (byte1 - byte0) + 3) / 4;
     // the last dword may reach past the caller's buffer by <4 bytes: read it bytewise
     const unsigned long long buf_end = (unsigned long long)pkts + total;
+    if ((unsigned long long)src >= (unsigned long long)pkts && (unsigned long long)(src + ndw) <= buf_end) {
+        // every dword of the range lies inside the caller's buffer (all tiles but the batch's first and last): the loads of four
+        // rounds in flight before the first LDS store
+        for (unsigned int k0 = 0; k0 < (unsigned int)ndw; k0 += 4 * DEC_BLOCK) {
+            unsigned int v[4];
+            #pragma unroll
+            for (int q = 0; q < 4; q++) { const unsigned int k = k0 + q * DEC_BLOCK + tid; v[q] = k < (unsigned int)ndw ? src[k] : 0u; }
+            #pragma unroll
+            for (int q = 0; q < 4; q++) { const unsigned int k = k0 + q * DEC_BLOCK + tid; if (k < (unsigned int)ndw) s_raw[k] = v[q]; }
+        }
+    } else
     for (size_t k = tid; k < ndw; k += DEC_BLOCK) {
         const unsigned long long a = (unsigned long long)(src + k);
         unsigned int v;
@@ -66,21 +77,28 @@ qs_decode_kernel(const unsigned char *__restrict__ pkts, size_t n, size_t stride
     int agent = 0, lmk = 0;
     if ((size_t)tid < nrec) {
         const size_t i = base + tid;
-        const unsigned char *r = (const unsigned char *)s_raw + mis + (size_t)tid * stride;
         const int len = lens ? (int)lens[i] : (int)stride;
         // :826-838 version by length
         if ((len == QS_PACKET_SIZE || len == QS_PACKET_SIZE_V1) && (size_t)len <= stride) {
-            unsigned char f[QS_PACKET_SIZE];
+            // the record's 42 bytes as eleven dwords: twelve aligned LDS reads shifted into place (v_alignbyte; the record starts
+            // at any byte), then every field by a shift of two of them -- not 42 byte reads.  Bytes past the record's length are
+            // never looked at (v1: the landmark byte, which is 0 then).
+            const unsigned int off = mis + (unsigned int)tid * (unsigned int)stride;
+            const unsigned int w0 = off >> 2, sh = off & 3u;
+            unsigned int d[12], r[11];
             #pragma unroll
-            for (int q = 0; q < QS_PACKET_SIZE; q++) f[q] = r[q < len ? q : 0];
-            agent = f[4];
-            lmk = (len == QS_PACKET_SIZE) ? f[41] : 0;
-            float x, y, yaw, d0, d1, d2, d3; int enc;
-            __builtin_memcpy(&x, f + 5, 4);  __builtin_memcpy(&y, f + 9, 4);
-            __builtin_memcpy(&yaw, f + 13, 4); __builtin_memcpy(&enc, f + 17, 4);
-            __builtin_memcpy(&d0, f + 25, 4); __builtin_memcpy(&d1, f + 29, 4);
-            __builtin_memcpy(&d2, f + 33, 4); __builtin_memcpy(&d3, f + 37, 4);
-            ok = f[0] == 'Q' && f[1] == 'S' && f[2] == 'R' && f[3] == 'L'      // :840
+            for (int q = 0; q < 12; q++) d[q] = s_raw[w0 + q];
+            #pragma unroll
+            for (int q = 0; q < 11; q++) r[q] = __builtin_amdgcn_alignbyte(d[q + 1], d[q], sh);
+            #define DEC_U32(p) ((p) % 4 == 0 ? r[(p) / 4] : __builtin_amdgcn_alignbyte(r[(p) / 4 + 1], r[(p) / 4], (p) % 4))
+            agent = (int)(r[1] & 0xffu);                                        // byte 4
+            lmk = (len == QS_PACKET_SIZE) ? (int)((r[10] >> 8) & 0xffu) : 0;    // byte 41
+            const float x = __uint_as_float(DEC_U32(5)), y = __uint_as_float(DEC_U32(9)), yaw = __uint_as_float(DEC_U32(13));
+            const int enc = (int)DEC_U32(17);
+            const float d0 = __uint_as_float(DEC_U32(25)), d1 = __uint_as_float(DEC_U32(29)), d2 = __uint_as_float(DEC_U32(33)),
+                        d3 = __uint_as_float(DEC_U32(37));
+            #undef DEC_U32
+            ok = r[0] == 0x4c525351u                                            // 'Q','S','R','L'  :840
                  && agent >= 1 && agent <= max_agent;                           // :842
             // CPython's int() raises on a non-finite pose (:123); the build drops the packet
             ok = ok && isfinite(x) && isfinite(y) && isfinite(yaw);
