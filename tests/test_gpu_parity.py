@@ -1261,12 +1261,15 @@ def pkg_replay_adversarial(pkg, n, seed):
     return replay.adversarial_stream(n, seed=seed, lo=-4.0, hi=4.0)
 
 
-def test_landmark_pile_dense_fallback(pkg):
+@pytest.mark.parametrize("max_agent,form", [(2, "auto"), (2, "window"), (16, "auto"), (16, "window")],
+                         ids=["2_bots_free", "2_bots_window", "16_bot_graph_dealt", "16_bot_graph_window"])
+def test_landmark_pile_dense_fallback(pkg, max_agent, form):
     """Row J1 (K4): the stream that defeats the bucket index -- a pile of landmarks in a neighbour bucket, out of reach of the
     query point and older than the query's own first match, so every query walks the whole chain.  Once the insert wave has
     seen a chain pass 64 pool nodes the library launches the chain kernel's DENSE variant, in which a runaway query scans the
     insertion-ordered landmark log instead (the reference's own loop, a wave wide).  Same closures, landmarks and drift as the
-    oracle -- whose scan IS the reference's -- before, while and after the variant changes."""
+    oracle -- whose scan IS the reference's -- before, while and after the variant changes.  Every chain kernel has the variant:
+    the free-running one (2 bots), the one that deals events to 14 owners (a graph sized for 16 bots), the per-window one."""
     P = pkg.protocol
     L, NQ = 6000, 900
     px, py, qx, qy = 0.05, 0.05, 0.75, 0.35                        # |PQ| = 0.76 m: neighbouring 0.6 m buckets, out of the 0.6 m radius
@@ -1277,9 +1280,10 @@ def test_landmark_pile_dense_fallback(pkg):
     tail = np.concatenate([pk(1, px, py, 40), pk(2, qx, qy, 40), pk(2, qx + 0.3, qy - 0.2, 60), pk(1, px + 0.2, py + 0.1, 60)])
     rng.shuffle(tail, axis=0)
     stream = np.concatenate([pk(1, px, py, L), pk(2, qx, qy, NQ), tail])
-    o = orc.OracleMapper(512, 0.05, -12.8, -12.8, 0.0)
+    o = orc.OracleMapper(512, 0.05, -12.8, -12.8, 0.0, max_agent=max_agent)
     o.feed_stream(stream)
-    with pkg.QuasarMapper(512, 0.05, -12.8, -12.8) as m:
+    with pkg.QuasarMapper(512, 0.05, -12.8, -12.8, max_agent=max_agent) as m:
+        m.set_chain_form(form)
         for lo, hi in ((0, 2500), (2500, L), (L, L + 300), (L + 300, len(stream))):      # the pile forms in the first batches
             m.ingest_array(stream[lo:hi])
         assert m.counters()["slam_misc_iters"] > 0                  # linear (log) scans happened: the DENSE variant ran
