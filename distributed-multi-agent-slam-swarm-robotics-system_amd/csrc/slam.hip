@@ -962,9 +962,12 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
 // Every wait of this kernel ends by the argument above.  A kernel that never ends would take the GPU with it, so the waits are
 // bounded all the same (~1 s): a wave that runs out of patience leaves a mark in QS_CNT_SLAM_ROUNDS (bit 40) and goes on --
 // the results are then wrong and every parity check says so -- instead of hanging.
+// (Once one wait has run out, every other one ends within 64 polls: a broken hand-over costs a second, not a second per event.)
 #define FR_SPIN_MAX (1u << 24)
-#define FR_SPIN(cond) do { unsigned int sp_ = 0; while (cond) { if (++sp_ > FR_SPIN_MAX) { if (lane == 0) atomicAdd(&counters[QS_CNT_SLAM_ROUNDS], 1ull << 40); break; } \
-                                                               __builtin_amdgcn_s_sleep(1); } } while (0)
+#define FR_SPIN(cond) do { unsigned int sp_ = 0; while (cond) {                                                                                   \
+        if (++sp_ > FR_SPIN_MAX) { if (lane == 0) atomicAdd(&counters[QS_CNT_SLAM_ROUNDS], 1ull << 40); break; }                                   \
+        if ((sp_ & 63u) == 0 && (__hip_atomic_load(&counters[QS_CNT_SLAM_ROUNDS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 40)) break;         \
+        __builtin_amdgcn_s_sleep(1); } } while (0)
 
 // one query: the reference's first match among the landmarks of type qtype with node index <= eff, within the radius of
 // (qx, qy); lane = (bucket of the 3 x 3 neighbourhood, entry of that bucket's current node).  LL_MAX: none.
@@ -1338,6 +1341,7 @@ qs_slam_chain_free_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuc
             const int k = rm == ~0ull ? 64 : (int)__builtin_ctzll(~rm);
             if (k == 0) {
                 if (++idle > FR_SPIN_MAX) { if (lane == 0) atomicAdd(&counters[QS_CNT_SLAM_ROUNDS], 1ull << 40); break; }   // (never: see FR_SPIN)
+                if ((idle & 63u) == 0 && (__hip_atomic_load(&counters[QS_CNT_SLAM_ROUNDS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 40)) break;
 #ifdef QS_FREE_PROF
                 pf_idle++;
 #endif
@@ -1449,8 +1453,11 @@ qs_slam_chain_free_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuc
 // The committer is the one of qs_slam_chain_free_kernel; "ready" = below the oldest event any owner is working on.
 // Waits point at OLDER events only (the agent's previous event, the frontier at q - MIN_POSES_BETWEEN, a ring slot held by an
 // older decision of the agent; the dispatcher at events committed), so the oldest undecided event can always go on.
-#define DY_RING 1024            // dispatcher -> owners: per event, the node index of the agent's previous event
-#define DY_RD 4                 // decisions an agent can be ahead of the committer
+#define DY_RING 512             // dispatcher -> owners: per event, the node index of the agent's previous event
+#define DY_PEND 256             // owners -> owners: per event under way or decided, the pose its landmark is stored at; an owner is
+                                // never more than DY_PEND - 64 events ahead of the committer
+#define DY_RING_SLOTS 1024      // decision slots in all: an agent can be 16 (up to 64 agents), 8 (up to 128) or 4 decisions ahead of the
+                                // committer -- the further, the larger the committer's batches get when it is what everybody waits for
 #define DY_OWNERS (CH_WAVES - 2)
 template <bool DENSE>
 __global__ void __launch_bounds__(CH_THREADS)
@@ -1466,8 +1473,9 @@ qs_slam_chain_dyn_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuck
     constexpr int NA = QS_MAX_AGENT + 1;
     constexpr long long LL_MIN_ = -LL_MAX - 1;
 
-    __shared__ long long q_idx[NA][DY_RD], q_midx[NA][DY_RD];                   // decisions: closing node; matched landmark's node
-    __shared__ double q_cdx[NA][DY_RD], q_cdy[NA][DY_RD];                       // the closure's correction (:314-315)
+    __shared__ long long q_idx[DY_RING_SLOTS], q_midx[DY_RING_SLOTS];           // decisions [agent][slot]: closing node; matched landmark's node
+    __shared__ double q_cdx[DY_RING_SLOTS], q_cdy[DY_RING_SLOTS];               // the closure's correction (:314-315)
+    const unsigned int DY_RD = nb <= 64 ? 16u : nb <= 128 ? 8u : 4u;            // (slots per agent; a power of two)
     __shared__ unsigned int s_push[NA], s_cons[NA];                             // decisions pushed by the owners / taken by the committer
     __shared__ double a_dx[NA], a_dy[NA];                                       // the agent's drift and last closure as of ...
     __shared__ long long a_last[NA], a_node[NA];                                // ... its event a_node (decided up to and including it)
@@ -1475,11 +1483,14 @@ qs_slam_chain_dyn_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuck
     __shared__ long long s_frontier, s_nmisc, s_nlms;
     __shared__ unsigned int s_head, s_disp, s_comm;   // events handed out / prepared by the dispatcher / committed (counts from e0)
     __shared__ long long d_ring[DY_RING], d_last[NA];
+    __shared__ long long p_node[DY_PEND];         // the event that has the slot (its node index), written after ...
+    __shared__ double p_x[DY_PEND], p_y[DY_PEND]; // ... the pose its landmark is appended at (:288: before its own closure)
     __shared__ unsigned int d_tag[NA];
     __shared__ double c_ddx[NA], c_ddy[NA];       // committer: every agent's drift as of the events it has passed
     __shared__ unsigned int c_apos[NA], c_tag[NA];
 
     const unsigned int e0 = sb.ev_base[g], e1 = sb.ev_base[g + 1];
+    for (int t = tid; t < DY_PEND; t += CH_THREADS) p_node[t] = LL_MIN_;
     for (int t = tid; t < NA; t += CH_THREADS) {
         s_push[t] = 0; s_cons[t] = 0; d_tag[t] = 0xffffffffu; c_tag[t] = 0xffffffffu; d_last[t] = LL_MIN_; a_node[t] = LL_MIN_;
         if (t < nb) {
@@ -1573,11 +1584,20 @@ qs_slam_chain_dyn_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuck
             pf_prev += __builtin_amdgcn_s_memtime() - tv_;
 #endif
             const long long last = a_last[qa];
+            const double odx = a_dx[qa], ody = a_dy[qa];
+            const double spx = rlf64(px_c, l), spy = rlf64(py_c, l);
+            const double qx = raw_pose ? spx : spx + odx, qy = raw_pose ? spy : spy + ody;       // rx += cdx  :856-857
+            // the pose this event's landmark is appended at (:288) is known from here on: posted for the queries of younger events,
+            // which then need not wait for the committer to put it into the index
+            {
+                FR_SPIN(r >= LD_RLX(&s_comm) + (unsigned int)(DY_PEND - QS_WAVE));  // (the slot's last holder is long committed)
+                const unsigned int ps = r % DY_PEND;
+                if (lane == 0) { p_x[ps] = qx; p_y[ps] = qy; }
+                CBAR();
+                if (lane == 0) ST_RLX(&p_node[ps], qidx);
+            }
             if (qidx - last >= min_between) {                                       // :304
-                const double odx = a_dx[qa], ody = a_dy[qa];
                 const long long fr0 = LD_RLX(&s_frontier);
-                const double spx = rlf64(px_c, l), spy = rlf64(py_c, l);
-                const double qx = raw_pose ? spx : spx + odx, qy = raw_pose ? spy : spy + ody;   // rx += cdx  :856-857
                 const int qtype = __builtin_amdgcn_readlane(type_c, l);
                 const long long limit = qidx - (min_between > 1 ? min_between : 1);  // :300; a node never sees its own landmark (:288)
                 long long gbest; double wx, wy;
@@ -1591,8 +1611,43 @@ qs_slam_chain_dyn_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuck
                     gbest = free_query<DENSE>(Gp, g_nodes, g_next, bg, qx, qy, qtype, fr < limit ? fr : limit, r2thr, nm, nl, lane, wx, wy, st_misc,
                                               fq_node0(bg, qx, qy, qtype, lane, qcx_, qcy_), false, FqRows{LL_MAX, LL_MAX, 0, 0, 0u});
                     if (gbest != LL_MAX || fr >= limit) break;                      // a match below the frontier is final; so is "none" once all are in
+                    // Nothing in the index up to fr.  The landmarks with fr < node <= limit are events the committer has not got to:
+                    // their poses are in the pending ring as soon as their owners have started on them -- which waits for older events
+                    // only.  64 events a round, youngest first; the OLDEST match is the reference's first match.
                     st_wait++;
-                    FR_SPIN(lds_ld64(&s_frontier) < limit);
+#if defined(QS_FREE_PROF) && QS_FREE_PROF == 6
+                    const unsigned long long tw_ = __builtin_amdgcn_s_memtime();
+#endif
+                    bool stale = false;
+                    for (unsigned int back = 0; back < r; back += QS_WAVE) {
+                        const long long jr = (long long)r - 1 - (long long)back - lane;
+                        const bool hv = jr >= 0;
+                        const long long nd = hv ? sb.ev_node[e0 + (unsigned int)jr] : LL_MIN_;
+                        const int ty = hv ? (int)sb.ev_type[e0 + (unsigned int)jr] : 0;
+                        const bool inr = hv && nd > fr && nd <= limit;
+                        const unsigned int ps = hv ? (unsigned int)jr % DY_PEND : 0u;
+                        // posted -- or, if the committer overtook it meanwhile (its slot may have a new holder), in the index by now
+                        FR_SPIN(__ballot(inr && LD_RLX(&p_node[ps]) != nd && LD_RLX(&s_frontier) < nd) != 0);
+                        CBAR();
+                        if (__ballot(inr && LD_RLX(&p_node[ps]) != nd)) { stale = true; break; }
+                        bool hit = false;
+                        double lx = 0, ly = 0;
+                        if (inr && ty == qtype) {
+                            lx = p_x[ps]; ly = p_y[ps];
+                            const double dx = qx - lx, dy = qy - ly;
+                            hit = dx * dx + dy * dy < r2thr;                        // :308-309
+                        }
+                        CBAR();
+                        if (__ballot(inr && LD_RLX(&p_node[ps]) != nd)) { stale = true; break; }   // (the pose read belongs to that event)
+                        const unsigned long long hm = __ballot(hit);
+                        if (hm) { const int w = 63 - __builtin_clzll(hm); gbest = rl64(nd, w); wx = rlf64(lx, w); wy = rlf64(ly, w); }
+                        if (!__ballot(hv && lane == QS_WAVE - 1 && nd > fr)) break;  // the round's oldest event is in the index already
+                    }
+#if defined(QS_FREE_PROF) && QS_FREE_PROF == 6
+                    pf_wait += __builtin_amdgcn_s_memtime() - tw_;                   // (profile build 6: the pending scan)
+#endif
+                    if (!stale) break;                                              // match or none: final (index up to fr, events up to limit)
+                    gbest = LL_MAX;                                                 // the index has grown under the scan: once more, from it
                 }
 #ifdef QS_FREE_PROF
                 pf_query += __builtin_amdgcn_s_memtime() - tq_;
@@ -1602,19 +1657,19 @@ qs_slam_chain_dyn_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuck
                     const double cdx = ex * corr, cdy = ey * corr;                  // :314-315
                     const unsigned int pq = s_push[qa];
                     unsigned int cq = LD_RLX(&s_cons[qa]);
-                    if (pq - cq >= (unsigned int)DY_RD) {
+                    if (pq - cq >= DY_RD) {
 #ifdef QS_FREE_PROF
                         const unsigned long long t_ = __builtin_amdgcn_s_memtime();
 #endif
-                        FR_SPIN(pq - (cq = LD_RLX(&s_cons[qa])) >= (unsigned int)DY_RD);
+                        FR_SPIN(pq - (cq = LD_RLX(&s_cons[qa])) >= DY_RD);
 #ifdef QS_FREE_PROF
                         pf_wait += __builtin_amdgcn_s_memtime() - t_;
 #endif
                     }
                     CBAR();
                     if (lane == 0) {
-                        const unsigned int sl = pq % DY_RD;
-                        q_idx[qa][sl] = qidx; q_midx[qa][sl] = gbest; q_cdx[qa][sl] = cdx; q_cdy[qa][sl] = cdy;
+                        const unsigned int sl = (unsigned int)qa * DY_RD + (pq & (DY_RD - 1));
+                        q_idx[sl] = qidx; q_midx[sl] = gbest; q_cdx[sl] = cdx; q_cdy[sl] = cdy;
                         a_dx[qa] = odx + cdx; a_dy[qa] = ody + cdy; a_last[qa] = qidx;      // :911-914, :318
                     }
                     CBAR();
@@ -1667,6 +1722,7 @@ qs_slam_chain_dyn_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuck
             const int k = rm == ~0ull ? 64 : (int)__builtin_ctzll(~rm);
             if (k == 0) {
                 if (++idle > FR_SPIN_MAX) { if (lane == 0) atomicAdd(&counters[QS_CNT_SLAM_ROUNDS], 1ull << 40); break; }   // (never: see FR_SPIN)
+                if ((idle & 63u) == 0 && (__hip_atomic_load(&counters[QS_CNT_SLAM_ROUNDS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 40)) break;
 #ifdef QS_FREE_PROF
                 pf_idle++;
 #endif
@@ -1694,9 +1750,9 @@ qs_slam_chain_dyn_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuck
                     const unsigned int dp = LD_RLX(&s_push[ag]);
                     dx = c_ddx[ag]; dy = c_ddy[ag];                                  // matched / stored at the pose BEFORE the closure (:288, :308)
                     CBAR();
-                    const unsigned int sl = dc % DY_RD;
-                    if (dc != dp && q_idx[ag][sl] == node) {                         // (else the agent's next decision is about a later event)
-                        midx = q_midx[ag][sl]; cdx = q_cdx[ag][sl]; cdy = q_cdy[ag][sl];
+                    const unsigned int sl = (unsigned int)ag * DY_RD + (dc & (DY_RD - 1));
+                    if (dc != dp && q_idx[sl] == node) {                             // (else the agent's next decision is about a later event)
+                        midx = q_midx[sl]; cdx = q_cdx[sl]; cdy = q_cdy[sl];
                         const double ndx = dx + cdx, ndy = dy + cdy;                 // drift_correction[agent] += ...  :911-914
                         const unsigned int apos = c_apos[ag];
                         sb.acl_node[apos] = node; sb.acl_dx[apos] = ndx; sb.acl_dy[apos] = ndy;
