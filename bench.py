@@ -384,7 +384,7 @@ def secondary_64_bots(pkg, replay, torch, dev, side, args, G, counts, bpg=2, ste
     for line in bad:
         print(f"PARITY MISMATCH (64 bots, {m.n_graphs} pose graphs): {line}", file=sys.stderr)
     n_graphs = m.n_graphs
-    free_running = m.chain_form() == "free"
+    free_running = m.chain_form() in ("free", "free_posting")
     m.close()
     win = max(cnt["slam_windows"], 1)
     return {"workload": f"configs[2]: 64 bots (own generator runs, seeds 42..105) in {n_graphs} pose graph{'s' if n_graphs > 1 else ''}, own room "
@@ -589,7 +589,7 @@ def run_rank(args):
     # which form of the chain kernel ran (csrc/slam.hip; qs_chain_form): free-running -- owner waves decide, a committer wave inserts
     # behind them, no per-window barrier -- or per-window (QS_CHAIN_AUTO picks it for streams whose queries mostly find nothing)
     agents_per_graph = bpg or max_agent
-    free_running = m.chain_form() == "free"
+    free_running = m.chain_form() in ("free", "free_posting")
     if chain_ms >= ray_ms:
         dom_ms = chain_ms
         win = max(cnt["slam_windows"], 1)

@@ -242,7 +242,7 @@ extern "C" int qs_create(const qs_config *cfg, qs_ctx **out)
     CREATE_CHK(hipHostMalloc((void **)&c->h_chain_stat, 8 * sizeof(unsigned int), hipHostMallocDefault));
     memset(c->h_chain_stat, 0, 8 * sizeof(unsigned int));
     CREATE_CHK(hipEventCreateWithFlags(&c->ev_chain_stat, hipEventDisableTiming));
-    if (const char *e = getenv("QS_CHAIN_MODE")) c->chain_form = strcmp(e, "window") == 0 ? QS_CHAIN_WINDOW : strcmp(e, "free") == 0 ? QS_CHAIN_FREE : QS_CHAIN_AUTO;
+    if (const char *e = getenv("QS_CHAIN_MODE")) c->chain_form = strcmp(e, "window") == 0 ? QS_CHAIN_WINDOW : strcmp(e, "free") == 0 ? QS_CHAIN_FREE : strcmp(e, "free_posting") == 0 ? QS_CHAIN_FREE_POSTING : QS_CHAIN_AUTO;
     CREATE_CHK(hipMalloc((void **)&c->d_graphs, (size_t)c->n_graphs * sizeof(QsGraphDev)));
     CREATE_CHK(hipMemset(c->d_graphs, 0, (size_t)c->n_graphs * sizeof(QsGraphDev)));
     c->h_graphs.assign(c->n_graphs, QsGraphDev{});
@@ -330,7 +330,7 @@ extern "C" int qs_set_stream(qs_ctx *c, void *hip_stream)
 extern "C" int qs_set_chain_form(qs_ctx *c, int form)
 {
     ARGCHK(c, c != nullptr);
-    ARGCHK(c, form == QS_CHAIN_AUTO || form == QS_CHAIN_FREE || form == QS_CHAIN_WINDOW);
+    ARGCHK(c, form == QS_CHAIN_AUTO || form == QS_CHAIN_FREE || form == QS_CHAIN_WINDOW || form == QS_CHAIN_FREE_POSTING);
     c->chain_form = form;
     return QS_OK;
 }
@@ -338,7 +338,7 @@ extern "C" int qs_set_chain_form(qs_ctx *c, int form)
 extern "C" int qs_chain_form(qs_ctx *c)
 {
     if (!c) return QS_E_INVAL;
-    return c->chain_last_free ? QS_CHAIN_FREE : QS_CHAIN_WINDOW;
+    return !c->chain_last_free ? QS_CHAIN_WINDOW : c->chain_last_posting ? QS_CHAIN_FREE_POSTING : QS_CHAIN_FREE;
 }
 
 extern "C" int qs_sync(qs_ctx *c)
@@ -529,11 +529,11 @@ static int io_reserve(qs_ctx *c, size_t bytes);
 // call that reads or hands out the grid, the counters or the pose graphs; qs_sync; before a stamp rebase) and dropped by
 // qs_reset.  The same synchronisation brings the graphs' real landmark / closure counts (capacity planning starts from them,
 // not from "every record so far was a landmark") and the pile flag of the loop-closure chain.
-// Which form of the loop-closure chain suits the stream (slam.hip, qs_launch_slam).  The kernels keep running totals in four
-// device words; every ingest asks for a copy of them into pinned memory behind itself and looks, before it launches its own
-// chain, at whatever copy has landed by then -- nobody waits.  What the per-window form counts as a miss (a query that found
-// nothing) includes what the free-running form counts (a decision that had to wait for the frontier), so a stream that sends
-// the free-running form away (> 1/8) is not sent back by the per-window form (< 1/16).
+// Which instantiation of the free-running loop-closure chain suits the stream (slam.hip, qs_launch_slam): with or without the
+// owners posting their landmarks' poses.  The kernels keep running totals in device words (decisions that had to wait for the
+// committer / scans of the posted poses; closures); every ingest asks for a copy of them into pinned memory behind itself and
+// looks, before it launches its own chain, at whatever copy has landed by then -- nobody waits.  More than 1 in 8: posting on;
+// fewer than 1 in 16: off again (both instantiations count the same events).
 static void chain_stats_poll(qs_ctx *c, bool synced)
 {
     if (!c->chain_stat_pending) return;
@@ -541,8 +541,11 @@ static void chain_stats_poll(qs_ctx *c, bool synced)
     c->chain_stat_pending = false;
     unsigned int *now = c->h_chain_stat, *seen = c->h_chain_stat + 4;
     const uint64_t f_miss = now[0] - seen[0], f_hit = now[1] - seen[1], w_miss = now[2] - seen[2], w_hit = now[3] - seen[3];
-    if (!c->chain_windowed) { if (f_miss + f_hit >= 256 && f_miss * 8 > f_hit) c->chain_windowed = true; }
-    else if (w_miss + w_hit >= 256 && w_miss * 16 < w_hit) c->chain_windowed = false;
+    (void)w_miss; (void)w_hit;                               // (the per-window form keeps its counts; nothing is decided from them now)
+    if (f_miss + f_hit >= 256) {
+        if (!c->chain_posting) { if (f_miss * 8 > f_hit) c->chain_posting = true; }
+        else if (f_miss * 16 < f_hit) c->chain_posting = false;
+    }
     for (int i = 0; i < 4; i++) seen[i] = now[i];
 }
 static int chain_stats_request(qs_ctx *c)

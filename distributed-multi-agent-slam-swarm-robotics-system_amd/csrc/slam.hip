@@ -959,6 +959,7 @@ qs_slam_chain_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGe
 // again; the owner with the oldest pending event never waits for anyone (everything older is final), so the scheme cannot
 // lock up; a full decision ring holds its owner back until the committer -- which then has work -- drains it.
 #define FR_RING 64
+#define FR_PEND 256            // pending-pose ring of the free-running kernel (events)
 // Every wait of this kernel ends by the argument above.  A kernel that never ends would take the GPU with it, so the waits are
 // bounded all the same (~1 s): a wave that runs out of patience leaves a mark in QS_CNT_SLAM_ROUNDS (bit 40) and goes on --
 // the results are then wrong and every parity check says so -- instead of hanging.
@@ -1103,7 +1104,11 @@ __device__ inline void lds_st32(unsigned int *p, unsigned int v) { __hip_atomic_
 
 // WAVES: 16, or 8 for graphs of up to 5 agents -- half the waves per SIMD is twice the registers per wave (256), and the owner keeps
 // two chunks of events and two decisions' bucket rows in registers.
-template <bool DENSE, int WAVES>
+// POST: the owners post their events' landmark poses for the others' queries (below).  It costs every decision ~240 cycles, and a
+// stream whose queries nearly always find their match in the index (the reference's sessions: 99.8 %) never looks at them: the
+// library runs the instantiation without it until a batch had more than one decision in eight wait for the committer
+// (qs_api.hip, chain_stats_poll).
+template <bool DENSE, int WAVES, bool POST>
 __global__ void __launch_bounds__(WAVES * QS_WAVE)
 qs_slam_chain_free_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBucketGeom bg, int bots_per_graph,
                           int max_agent, int min_between, double r2thr, double corr,
@@ -1132,14 +1137,22 @@ qs_slam_chain_free_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuc
     // committer's own: every agent's drift as of the events it has passed, and where the agent's next closure record goes
     __shared__ double c_ddx[NA], c_ddy[NA];
     __shared__ unsigned int c_apos[NA];
+    // Landmarks that are decided about but not in the index yet: every owner posts the pose each of its events' landmarks is appended
+    // at (:288) as it passes the event, in a ring by position in the event list; a query that finds nothing in the index looks
+    // there for what lies between the frontier and its limit instead of waiting for the committer (FR_PEND - 64: how far an owner
+    // may be ahead of the committer).
+    __shared__ long long p_node[POST ? FR_PEND : 1];   // the event that has the slot (its node index), written after ...
+    __shared__ double p_x[POST ? FR_PEND : 1], p_y[POST ? FR_PEND : 1];   // ... its pose
+    __shared__ unsigned int s_comm;               // events committed (count from e0): where the frontier stands in the list
 
     const unsigned int e0 = sb.ev_base[g], e1 = sb.ev_base[g + 1];
+    if (POST) for (int t = tid; t < FR_PEND; t += THREADS) p_node[t] = -LL_MAX - 1;
     for (int t = tid; t < NA; t += THREADS) {
         s_push[t] = 0; s_cons[t] = 0;
         if (t < nb) { c_ddx[t] = drift[2 * (bot0 + t)]; c_ddy[t] = drift[2 * (bot0 + t) + 1]; c_apos[t] = sb.agent_ev[bot0 + t]; }
     }
     if (tid < AGW) s_prog[tid] = tid < n_ow ? (e0 < e1 ? sb.ev_node[e0] : LL_MAX) : LL_MAX;
-    if (tid == 0) { s_frontier = e0 < e1 ? sb.ev_node[e0] - 1 : LL_MAX; s_nmisc = Gp->n_misc; s_nlms = Gp->n_lms; }
+    if (tid == 0) { s_frontier = e0 < e1 ? sb.ev_node[e0] - 1 : LL_MAX; s_nmisc = Gp->n_misc; s_nlms = Gp->n_lms; s_comm = 0; }
     __syncthreads();
 
     if (wave >= 1 && wave <= n_ow) {
@@ -1186,6 +1199,21 @@ qs_slam_chain_free_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuc
             if (q0 + QS_WAVE < e1) load_chunk(q0 + QS_WAVE, ag_n, idx_n, type_n, px_n, py_n, nf_n);
             const unsigned long long own = __ballot(ag == a);
             unsigned long long done = 0;                                            // own lanes decided so far
+            unsigned long long posted = 0;                                          // own lanes whose landmark pose is in the pending ring
+            // own events up to lane hi (with the agent's drift as it is now: the events since its last closure)
+            auto post_upto = [&](int hi) {
+                if (!POST) return;
+                const unsigned long long m = own & ~posted & ((2ull << hi) - 1);
+                if ((m >> lane) & 1) {
+                    const unsigned int ps = (q0 - e0 + (unsigned int)lane) % FR_PEND;
+                    p_x[ps] = raw_pose ? px : px + c_dx; p_y[ps] = raw_pose ? py : py + c_dy;   // rx += cdx  :856-857
+                }
+                __asm__ volatile("" ::: "memory");
+                if ((m >> lane) & 1) __hip_atomic_store(&p_node[(q0 - e0 + (unsigned int)lane) % FR_PEND], idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                posted |= m;
+            };
+            // (a slot's last holder is long committed)
+            if (POST && own) FR_SPIN(q0 - e0 + QS_WAVE > __hip_atomic_load(&s_comm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + (unsigned int)(FR_PEND - QS_WAVE));
             // the events that may close a loop (:304: their agent is past its cool-down); the ones before the first need no decision
             auto eligible = [&]() -> unsigned long long {
                 return own & ~done & __ballot(idx - c_last >= min_between);
@@ -1206,6 +1234,7 @@ qs_slam_chain_free_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuc
                 // (the frontier first: the rows are asked for after it is read -- an older value is only more cautious)
                 fr_rows = __hip_atomic_load(&s_frontier, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 f = __ffsll((long long)e_) - 1;
+                post_upto(f);
                 qidx = rl64(idx, f);
                 const double spx = rlf64(px, f), spy = rlf64(py, f);
                 qx = raw_pose ? spx : spx + c_dx; qy = raw_pose ? spy : spy + c_dy;               // rx += cdx  :856-857
@@ -1220,6 +1249,7 @@ qs_slam_chain_free_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuc
                 const int qa = a;
                 const long long qidx_c = qidx;                                      // (this decision's: start_decision below moves on)
                 const double qx_c = qx, qy_c = qy;
+                const int f_c = f, qtype_c = qtype;
                 // :300 -- and a node never sees its own landmark (appended after the check, :288): with MIN_POSES_BETWEEN < 1
                 // the newest landmark a query can see is still the one before it
                 const long long limit = qidx_c - (min_between > 1 ? min_between : 1);
@@ -1231,15 +1261,50 @@ qs_slam_chain_free_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuc
                     bool pre = true;
                     for (long long fr = fr_rows;;) {
                         const long long nm = s_nmisc, nl = DENSE ? s_nlms : 0;
-                        gbest = free_query<DENSE>(Gp, g_nodes, g_next, bg, qx_c, qy_c, qtype, fr < limit ? fr : limit, r2thr, nm, nl, lane, wx, wy, st_misc,
+                        gbest = free_query<DENSE>(Gp, g_nodes, g_next, bg, qx_c, qy_c, qtype_c, fr < limit ? fr : limit, r2thr, nm, nl, lane, wx, wy, st_misc,
                                                   node0, pre, rows);
                         if (gbest != LL_MAX || fr >= limit) break;                  // a match below the frontier is final; so is "none" once all are in
                         pre = false;
-                        if (lds_ld64(&s_frontier) <= fr) {                          // nothing new since those rows: the committer has to come closer
-                            st_wait++;
-                            publish_prog(qidx_c);                                   // (it has to get past this owner's older events)
-                            FR_SPIN(lds_ld64(&s_frontier) < limit);
+                        // Nothing in the index up to fr.  The landmarks with fr < node <= limit are events the committer has not got
+                        // to: their poses are in the pending ring once their owners have passed them.  64 events a round, youngest
+                        // first; the OLDEST match is the reference's first match.
+                        st_wait++;
+                        publish_prog(qidx_c);                                       // (the committer has to get past this owner's older events)
+                        if (!POST) {                                                // wait until it has everything up to the limit in the index
+                            if (lds_ld64(&s_frontier) <= fr) FR_SPIN(lds_ld64(&s_frontier) < limit);
+                            fr = lds_ld64(&s_frontier);
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");    // the index as of that frontier, not older
+                            continue;
                         }
+                        bool stale = false;
+                        const unsigned int r_me = q0 - e0 + (unsigned int)f_c;      // this event's place in the list
+                        for (unsigned int back = 0; back < r_me; back += QS_WAVE) {
+                            const long long jr = (long long)r_me - 1 - (long long)back - lane;
+                            const bool hv = jr >= 0;
+                            const long long nd = hv ? sb.ev_node[e0 + (unsigned int)jr] : -LL_MAX - 1;
+                            const int ty = hv ? (int)sb.ev_type[e0 + (unsigned int)jr] : 0;
+                            const bool inr = hv && nd > fr && nd <= limit;
+                            const unsigned int ps = hv ? (unsigned int)jr % FR_PEND : 0u;
+                            // posted -- or, if the committer overtook it meanwhile (its slot may have a new holder), in the index by now
+                            FR_SPIN(__ballot(inr && __hip_atomic_load(&p_node[ps], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != nd &&
+                                             __hip_atomic_load(&s_frontier, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < nd) != 0);
+                            __asm__ volatile("" ::: "memory");
+                            if (__ballot(inr && __hip_atomic_load(&p_node[ps], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != nd)) { stale = true; break; }
+                            bool hit = false;
+                            double lx = 0, ly = 0;
+                            if (inr && ty == qtype_c) {
+                                lx = p_x[ps]; ly = p_y[ps];
+                                const double dx = qx_c - lx, dy = qy_c - ly;
+                                hit = dx * dx + dy * dy < r2thr;                    // :308-309
+                            }
+                            __asm__ volatile("" ::: "memory");
+                            if (__ballot(inr && __hip_atomic_load(&p_node[ps], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != nd)) { stale = true; break; }
+                            const unsigned long long hm = __ballot(hit);
+                            if (hm) { const int w = 63 - __builtin_clzll(hm); gbest = rl64(nd, w); wx = rlf64(lx, w); wy = rlf64(ly, w); }
+                            if (!__ballot(hv && lane == QS_WAVE - 1 && nd > fr)) break;  // the round's oldest event is in the index already
+                        }
+                        if (!stale) break;                                          // match or none: final (index up to fr, events up to limit)
+                        gbest = LL_MAX;                                             // the index has grown under the scan: once more, from it
                         fr = lds_ld64(&s_frontier);
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");        // the index as of that frontier, not older
                     }
@@ -1247,7 +1312,7 @@ qs_slam_chain_free_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuc
 #ifdef QS_FREE_PROF
                 pf_query += __builtin_amdgcn_s_memtime() - tq_;
 #endif
-                done |= (2ull << f) - 1;                                            // (lanes up to f: decided)
+                done |= (2ull << f_c) - 1;                                          // (lanes up to f: decided)
                 double cdx = 0, cdy = 0;
                 if (gbest != LL_MAX) {
                     const double ex = wx - qx_c, ey = wy - qy_c;                    // :311-312
@@ -1289,6 +1354,7 @@ qs_slam_chain_free_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuc
                 pf_post += __builtin_amdgcn_s_memtime() - tq_;                      // (query + everything after it)
 #endif
             }
+            post_upto(QS_WAVE - 1);                                                 // (the agent's events after its last decision of the chunk)
             publish_prog(next_first);
         }
         publish_prog(LL_MAX);
@@ -1417,6 +1483,7 @@ qs_slam_chain_free_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuc
             if (lane == 0) {
                 s_nmisc = n_misc; s_nlms = n_lms;
                 lds_st64(&s_frontier, next_node == LL_MAX ? LL_MAX : next_node - 1);
+                __hip_atomic_store(&s_comm, e + k - e0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             e += k;
             node = node_n; ag = ag_n; type_l = type_n; px_l = px_n; py_l = py_n;
@@ -1923,22 +1990,31 @@ hipError_t qs_launch_slam(qs_ctx *c, size_t n, bool raw_pose)
                            c->bots_per_graph, c->cfg.max_agent, c->win, c->cfg.min_poses_between, c->r2_threshold,                          \
                            c->cfg.closure_correction, c->d_drift, c->d_last_closure, c->d_counters, raw_pose ? 1 : 0, c->d_flags + QS_FLAG_PILE)
     const bool one = c->bots_per_graph <= CH_AGW;
-    // which form (qs_set_chain_form; QS_CHAIN_MODE at qs_create).  Graphs of up to CH_AGW agents, left to themselves: the
-    // free-running form until a batch had it wait for the frontier in more than 1 of 8 decisions -- a stream whose queries mostly
-    // find nothing makes every other decision wait for the committer, and the per-window kernel, which sees the newest landmarks
-    // in LDS, is the faster one there --, the per-window form until fewer than 1 in 16 of its queries come back empty
+    // which form (qs_set_chain_form; QS_CHAIN_MODE at qs_create).  Left to itself the library runs the free-running form; for
+    // graphs of up to CH_AGW agents without the posting of poses until a batch had more than 1 decision in 8 wait for the
+    // committer -- a stream whose queries mostly find nothing in the index --, with it until fewer than 1 in 16 need it
     // (chain_stats_poll in qs_api.hip reads the counts, without waiting for anything).  Same results either way.
-    const bool free_mode = c->chain_form == QS_CHAIN_FREE || (c->chain_form == QS_CHAIN_AUTO && !(one && c->chain_windowed));
+    const bool free_mode = c->chain_form != QS_CHAIN_WINDOW;
+    c->chain_last_posting = false;
     c->chain_last_free = free_mode;
-#define FR_LAUNCH(DENSE_, WAVES_) hipLaunchKernelGGL((qs_slam_chain_free_kernel<DENSE_, WAVES_>), dim3(G), dim3(WAVES_ * QS_WAVE), 0, c->stream, c->d_graphs, sb, c->bg, \
+#define FR_LAUNCH(DENSE_, WAVES_, POST_) hipLaunchKernelGGL((qs_slam_chain_free_kernel<DENSE_, WAVES_, POST_>), dim3(G), dim3(WAVES_ * QS_WAVE), 0, c->stream, c->d_graphs, sb, c->bg, \
                            c->bots_per_graph, c->cfg.max_agent, c->cfg.min_poses_between, c->r2_threshold,                                  \
                            c->cfg.closure_correction, c->d_drift, c->d_last_closure, c->d_counters, raw_pose ? 1 : 0, c->d_flags + QS_FLAG_PILE)
 #define DY_LAUNCH(DENSE_) hipLaunchKernelGGL((qs_slam_chain_dyn_kernel<DENSE_>), dim3(G), dim3(CH_THREADS), 0, c->stream, c->d_graphs, sb, c->bg, \
                            c->bots_per_graph, c->cfg.max_agent, c->cfg.min_poses_between, c->r2_threshold,                                  \
                            c->cfg.closure_correction, c->d_drift, c->d_last_closure, c->d_counters, raw_pose ? 1 : 0, c->d_flags + QS_FLAG_PILE)
     if (free_mode) {
-        if (one && c->bots_per_graph <= 5) { if (c->pile_mode) FR_LAUNCH(true, 8); else FR_LAUNCH(false, 8); }
-        else if (one) { if (c->pile_mode) FR_LAUNCH(true, 16); else FR_LAUNCH(false, 16); }
+        if (one) {
+            const bool post = c->chain_form == QS_CHAIN_FREE_POSTING || (c->chain_form == QS_CHAIN_AUTO && c->chain_posting);
+            const int sel = (c->pile_mode ? 4 : 0) | (c->bots_per_graph <= 5 ? 2 : 0) | (post ? 1 : 0);
+            switch (sel) {
+            case 0: FR_LAUNCH(false, 16, false); break;  case 1: FR_LAUNCH(false, 16, true); break;
+            case 2: FR_LAUNCH(false, 8, false); break;   case 3: FR_LAUNCH(false, 8, true); break;
+            case 4: FR_LAUNCH(true, 16, false); break;   case 5: FR_LAUNCH(true, 16, true); break;
+            case 6: FR_LAUNCH(true, 8, false); break;    default: FR_LAUNCH(true, 8, true); break;
+            }
+            c->chain_last_posting = post;
+        }
         else { if (c->pile_mode) DY_LAUNCH(true); else DY_LAUNCH(false); }
     }
 #undef DY_LAUNCH

@@ -403,16 +403,17 @@ class QuasarMapper:
                   "qs_nn_search")
         return corr, d2, (float(ms[0]), float(ms[1]))
 
-    CHAIN_FORMS = {"auto": 0, "free": 1, "window": 2}
+    CHAIN_FORMS = {"auto": 0, "free": 1, "window": 2, "free_posting": 3}
 
     def set_chain_form(self, form):
-        """Which device form of the loop-closure chain runs: "auto" (default), "free" (free-running), "window" (one barrier
-        per window).  Same closures, landmarks and drifts either way (dual_bot_mapper.py:292-326)."""
+        """Which device form of the loop-closure chain runs: "auto" (default), "free" (free-running), "free_posting" (free-running,
+        the owner waves post their landmarks' poses for each other), "window" (one barrier per window).  Same closures,
+        landmarks and drifts whichever (dual_bot_mapper.py:292-326)."""
         self._chk(self._L.qs_set_chain_form(self._h, self.CHAIN_FORMS[form]), "qs_set_chain_form")
 
     def chain_form(self):
-        """The form the last ingest used: "free" or "window"."""
-        return {1: "free", 2: "window"}[self._L.qs_chain_form(self._h)]
+        """The form the last ingest used: "free", "free_posting" or "window"."""
+        return {1: "free", 2: "window", 3: "free_posting"}[self._L.qs_chain_form(self._h)]
 
     def mfma_f64_rate(self):
         """Measured dense fp64 MFMA rate of this GPU in TFLOP/s (diagnostic)."""

@@ -238,16 +238,18 @@ int qs_icp(qs_ctx *ctx, const double *src_xy, size_t n_src, const double *dst_xy
  * ms (may be NULL): HIP-event milliseconds of {the search kernel, the operand preparation}. */
 int qs_nn_search(qs_ctx *ctx, const double *src_xy, size_t n_src, const double *dst_xy, size_t n_dst,
                  double max_dist, int32_t mode, int32_t *corr, double *d2, float ms[2]);
-/* Loop-closure chain (PoseGraphSLAM.check_loop_closure, dual_bot_mapper.py:292-326): which of the two device forms runs --
- * same closures, landmarks and drifts either way.  QS_CHAIN_AUTO (default; the environment's QS_CHAIN_MODE=free|window at
- * qs_create overrides): graphs of more than 13 bots the free-running form; smaller graphs the free-running form as long as
- * its decisions rarely have to wait for landmarks still on their way into the index, the per-window form for streams whose
- * queries mostly find nothing (decided from counts the kernels leave: every ingest has them copied to pinned memory behind
- * itself and the next ingest looks at whatever has arrived -- nobody waits; kept over qs_reset: it describes the stream, not
- * the session).  qs_chain_form: the form the last ingest used (QS_CHAIN_FREE / _WINDOW). */
+/* Loop-closure chain (PoseGraphSLAM.check_loop_closure, dual_bot_mapper.py:292-326): which device form runs -- same closures,
+ * landmarks and drifts whichever.  QS_CHAIN_AUTO (default; the environment's QS_CHAIN_MODE=free|free_posting|window at qs_create
+ * overrides): the free-running form; for graphs of up to 13 bots without the owner waves posting their landmarks' poses for each
+ * other (QS_CHAIN_FREE) as long as its decisions rarely find nothing in the index, with it (QS_CHAIN_FREE_POSTING) for streams
+ * whose queries mostly find nothing -- decided from counts the kernels leave: every ingest has them copied to pinned memory behind
+ * itself and the next ingest looks at whatever has arrived, nobody waits; kept over qs_reset: it describes the stream, not the
+ * session.  QS_CHAIN_WINDOW: the per-window kernel (one barrier per window of MIN_POSES_BETWEEN nodes), kept as second opinion.
+ * qs_chain_form: the form the last ingest used. */
 #define QS_CHAIN_AUTO 0
 #define QS_CHAIN_FREE 1
 #define QS_CHAIN_WINDOW 2
+#define QS_CHAIN_FREE_POSTING 3
 int qs_set_chain_form(qs_ctx *ctx, int form);
 int qs_chain_form(qs_ctx *ctx);
 

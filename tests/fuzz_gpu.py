@@ -67,7 +67,7 @@ for it in range(n_iter):
     o.set_closure_params(radius, mb, corr)
     o.feed_stream(stream)
     cuts = sorted(set([0, n] + [int(c) for c in rng.integers(0, n, int(rng.integers(0, 4)))]))
-    form = str(rng.choice(["auto", "free", "window"]))
+    form = str(rng.choice(["auto", "free", "free_posting", "window"]))
     with pkg.QuasarMapper(512, 0.05, -12.8, -12.8, max_agent=nb, bots_per_graph=bpg, closure_radius=radius,
                           min_poses_between=mb, closure_correction=corr) as m:
         m.set_chain_form(form)
