@@ -533,7 +533,9 @@ static int io_reserve(qs_ctx *c, size_t bytes);
 // owners posting their landmarks' poses.  The kernels keep running totals in device words (decisions that had to wait for the
 // committer / scans of the posted poses; closures); every ingest asks for a copy of them into pinned memory behind itself and
 // looks, before it launches its own chain, at whatever copy has landed by then -- nobody waits.  More than 1 in 8: posting on;
-// fewer than 1 in 16: off again (both instantiations count the same events).
+// fewer than 1 in 16: off again (both instantiations count the same events); more scans than closures even so (a stream
+// that hardly ever matches: the adversarial one spread over an 8192^2 world): the per-window kernel, until its queries
+// that find nothing are fewer than half its closures.
 static void chain_stats_poll(qs_ctx *c, bool synced)
 {
     if (!c->chain_stat_pending) return;
@@ -541,9 +543,10 @@ static void chain_stats_poll(qs_ctx *c, bool synced)
     c->chain_stat_pending = false;
     unsigned int *now = c->h_chain_stat, *seen = c->h_chain_stat + 4;
     const uint64_t f_miss = now[0] - seen[0], f_hit = now[1] - seen[1], w_miss = now[2] - seen[2], w_hit = now[3] - seen[3];
-    (void)w_miss; (void)w_hit;                               // (the per-window form keeps its counts; nothing is decided from them now)
-    if (f_miss + f_hit >= 256) {
+    if (c->chain_windowed) { if (w_miss + w_hit >= 256 && w_miss * 2 < w_hit) c->chain_windowed = false; }   // (back to posting)
+    else if (f_miss + f_hit >= 256) {
         if (!c->chain_posting) { if (f_miss * 8 > f_hit) c->chain_posting = true; }
+        else if (f_miss > f_hit) c->chain_windowed = true;   // more scans than closures: the per-window kernel's LDS windows are cheaper
         else if (f_miss * 16 < f_hit) c->chain_posting = false;
     }
     for (int i = 0; i < 4; i++) seen[i] = now[i];

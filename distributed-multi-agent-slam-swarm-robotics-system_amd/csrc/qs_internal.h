@@ -202,6 +202,7 @@ struct qs_ctx {
     int chain_form = 0;                          // QS_CHAIN_AUTO / _FREE / _WINDOW (qs_set_chain_form)
     bool chain_posting = false;                  // QS_CHAIN_AUTO's present choice for graphs of few agents: the free-running kernel WITH the
                                                  // owners posting their landmarks' poses (slam.hip, qs_launch_slam)
+    bool chain_windowed = false;                 // ... and beyond that: the per-window kernel (even with posted poses most queries find nothing)
     bool chain_last_free = true, chain_last_posting = false;   // the form the last launch used
     unsigned int *h_chain_stat = nullptr;        // pinned: [0..3] the four running totals as copied last, [4..7] as consumed last
     hipEvent_t ev_chain_stat = nullptr;          // ... complete when the copy has landed

@@ -1992,9 +1992,10 @@ hipError_t qs_launch_slam(qs_ctx *c, size_t n, bool raw_pose)
     const bool one = c->bots_per_graph <= CH_AGW;
     // which form (qs_set_chain_form; QS_CHAIN_MODE at qs_create).  Left to itself the library runs the free-running form; for
     // graphs of up to CH_AGW agents without the posting of poses until a batch had more than 1 decision in 8 wait for the
-    // committer -- a stream whose queries mostly find nothing in the index --, with it until fewer than 1 in 16 need it
+    // committer -- a stream whose queries mostly find nothing in the index --, with it until fewer than 1 in 16 need it, and the
+    // per-window kernel while even so there are more scans than closures
     // (chain_stats_poll in qs_api.hip reads the counts, without waiting for anything).  Same results either way.
-    const bool free_mode = c->chain_form != QS_CHAIN_WINDOW;
+    const bool free_mode = c->chain_form != QS_CHAIN_WINDOW && !(c->chain_form == QS_CHAIN_AUTO && one && c->chain_windowed);
     c->chain_last_posting = false;
     c->chain_last_free = free_mode;
 #define FR_LAUNCH(DENSE_, WAVES_, POST_) hipLaunchKernelGGL((qs_slam_chain_free_kernel<DENSE_, WAVES_, POST_>), dim3(G), dim3(WAVES_ * QS_WAVE), 0, c->stream, c->d_graphs, sb, c->bg, \

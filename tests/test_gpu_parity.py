@@ -1262,6 +1262,23 @@ def pkg_replay_adversarial(pkg, n, seed):
     return replay.adversarial_stream(n, seed=seed, lo=-4.0, hi=4.0)
 
 
+def test_chain_form_for_a_stream_that_hardly_ever_matches(pkg):
+    """QS_CHAIN_AUTO's third state: uniform-random poses over a world so large that most queries find nothing even among the
+    posted poses (more scans than closures) -- the per-window kernel, whose LDS windows are the cheaper way to find nothing.
+    free -> free_posting -> window, the oracle's results throughout."""
+    replay = _replay(pkg)
+    parts = [replay.adversarial_stream(12000, seed=20 + i, lo=-50.0, hi=50.0) for i in range(4)]
+    o = orc.OracleMapper(2048, 0.05, -51.2, -51.2, 0.0)
+    with pkg.QuasarMapper(2048, 0.05, -51.2, -51.2) as m:
+        forms = []
+        for part in parts:
+            m.ingest_array(part); o.feed_stream(part)
+            forms.append(m.chain_form())
+        assert forms == ["free", "free_posting", "window", "window"], forms
+        assert (m.grid_i8() == o.grid).all()
+        _chain_equal(m, o, 1, 2)
+
+
 @pytest.mark.parametrize("max_agent,form", [(2, "auto"), (2, "free_posting"), (2, "window"), (16, "auto"), (16, "window")],
                          ids=["2_bots_free", "2_bots_free_posting", "2_bots_window", "16_bot_graph_dealt", "16_bot_graph_window"])
 def test_landmark_pile_dense_fallback(pkg, max_agent, form):
