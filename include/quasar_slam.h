@@ -244,7 +244,8 @@ int qs_nn_search(qs_ctx *ctx, const double *src_xy, size_t n_src, const double *
  * other (QS_CHAIN_FREE) as long as its decisions rarely find nothing in the index, with it (QS_CHAIN_FREE_POSTING) for streams
  * whose queries mostly find nothing -- decided from counts the kernels leave: every ingest has them copied to pinned memory behind
  * itself and the next ingest looks at whatever has arrived, nobody waits; kept over qs_reset: it describes the stream, not the
- * session.  QS_CHAIN_WINDOW: the per-window kernel (one barrier per window of MIN_POSES_BETWEEN nodes), kept as second opinion.
+ * session.  QS_CHAIN_WINDOW: the per-window kernel (one barrier per window of MIN_POSES_BETWEEN nodes): the second opinion of the
+ * tests, and QS_CHAIN_AUTO's last resort for a stream that hardly ever matches (more scans of posted poses than closures).
  * qs_chain_form: the form the last ingest used. */
 #define QS_CHAIN_AUTO 0
 #define QS_CHAIN_FREE 1
