@@ -1756,7 +1756,7 @@ qs_slam_chain_dyn_kernel(QsGraphDev *__restrict__ graphs, QsSlamBatch sb, QsBuck
                              atomicAdd(&counters[QS_CNT_SLAM_NODE_ITERS], __builtin_amdgcn_s_memtime() - pf_total0); }
 #endif
         }
-    } else {
+    } else if (wave == CH_WAVES - 1) {
         // =================================== the committer ===================================
         const QsGraphDev G = *Gp;
         long long n_lms = G.n_lms, n_misc = G.n_misc, n_cls = G.n_cls;
