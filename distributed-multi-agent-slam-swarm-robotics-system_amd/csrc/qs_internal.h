@@ -207,6 +207,7 @@ struct qs_ctx {
     unsigned int *h_chain_stat = nullptr;        // pinned: [0..3] the four running totals as copied last, [4..7] as consumed last
     hipEvent_t ev_chain_stat = nullptr;          // ... complete when the copy has landed
     bool chain_stat_pending = false;
+    unsigned int chain_stat_tick = 0;            // ingests since qs_create (the copy is asked for by one in four)
     uint64_t edge_rays_total = 0;                // exact-trig mode: rays resolved on the host since the last reset
     uint64_t edge_overflow_total = 0;            //   ... and rays that found the list full (cast with the device's trig)
 
