@@ -257,7 +257,7 @@ int qs_chain_form(qs_ctx *ctx);
 /* diagnostic: measured dense fp64 MFMA rate of this GPU (TFLOP/s), the ceiling qs_nn_search mode 2 is priced against */
 int qs_diag_mfma_f64_rate(qs_ctx *ctx, double *tflops);
 /* diagnostic: latencies of the primitives one loop-closure decision chains together, measured on this GPU by ONE workgroup
- * (as qs_slam_chain_kernel runs), in shader-clock cycles:
+ * (as the loop-closure chain kernels run), in shader-clock cycles:
  *   out[0] dependent global load, L2 hit     out[1] dependent global load, L1 hit     out[2] dependent LDS read
  *   out[3] dependent v_fma_f64               out[4] dependent DPP / VALU step          out[5] v_readlane -> VALU step
  *   out[6] workgroup barrier + LDS fences, 16 waves      out[7] same, 5 waves          out[8] shader clock in MHz */
@@ -306,7 +306,7 @@ int qs_counters(qs_ctx *ctx, uint64_t out[QS_CNT_N]);
  * launch count per stage since the last call with reset != 0. */
 enum { QS_STAGE_DECODE = 0, QS_STAGE_SLAM, QS_STAGE_RAYCAST, QS_STAGE_EKF,
        /* single kernels inside the stages above (their time is part of the stage's too) */
-       QS_STAGE_SLAM_CHAIN,                     /* qs_slam_chain_kernel alone (inside SLAM) */
+       QS_STAGE_SLAM_CHAIN,                     /* the loop-closure chain kernel alone (inside SLAM) */
        QS_STAGE_RC_RAYS, QS_STAGE_RC_SORT, QS_STAGE_RC_RASTER,   /* tiled raycast: pass A; passes B + C; pass D */
        QS_STAGE_N };
 int qs_timing_enable(qs_ctx *ctx, int32_t enable);
